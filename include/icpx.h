@@ -1,0 +1,178 @@
+/*
+ * icpx.h — C ABI of libicpx, the MI355X (gfx950) implementation of the ICP
+ * correspondence-and-alignment hot path.
+ *
+ * The reference has no FFI layer; its hot path is reached through the VTK
+ * class surface of vtkICP / vtkPolyDataCorrespondenceFilter.  Each entry point
+ * below names the reference code it replaces (paths relative to the reference
+ * tree).  Conventions:
+ *   - every function returns 0 on success or a negative ICPX_E_* code;
+ *     icpx_last_error() gives the message of the calling thread's last failure;
+ *   - no C++ exception crosses this boundary;
+ *   - matrices are row-major 4x4 doubles that act on column vectors
+ *     (vtkMatrix4x4 element order);
+ *   - the caller owns every host buffer it passes in; a context owns its
+ *     device memory; one context is used by one host thread at a time;
+ *   - point, triangle and landmark counts are below 2^31.
+ */
+#ifndef ICPX_H
+#define ICPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+#define ICPX_OK 0
+#define ICPX_E_INVALID (-1)  /* bad argument, or a call out of order */
+#define ICPX_E_HIP (-2)      /* a HIP runtime call failed */
+#define ICPX_E_NOMEM (-3)
+#define ICPX_E_FEW (-4)      /* too few correspondences to solve */
+
+#define ICPX_METRIC_POINT_TO_POINT 0 /* vtkICP::MetricPointToPoint, ICP/vtkICP.h:36 */
+#define ICPX_METRIC_POINT_TO_PLANE 1 /* vtkICP::MetricPointToPlane, ICP/vtkICP.h:37 */
+#define ICPX_METRIC_PLANE_TO_PLANE 2 /* vtkICP::MetricPlaneToPlane (symmetric), ICP/vtkICP.h:38 */
+
+/* Length of the partial-sum vector one search pass produces.  Slot 0 is the
+ * number of accepted correspondences, slot 1 the sum of |s - t| over them; the
+ * rest are the metric's raw moments (layout private to icpx_solve).  Partial
+ * sums of several contexts (GPUs) over disjoint source shards add
+ * element-wise. */
+#define ICPX_NSUMS 40
+
+  typedef struct icpx_ctx icpx_ctx;
+
+  /* Message of the calling thread's most recent failure ("" if none). */
+  const char* icpx_last_error(void);
+
+  /* Number of HIP devices visible to the process (0 if none / no driver). */
+  int icpx_device_count(void);
+
+  /* Create / destroy a context bound to one GPU.  A process that shards the
+   * source over several GPUs makes one context per device (or one process per
+   * GPU with one context each).  Replaces the construction of
+   * vtkPolyDataCorrespondenceFilter + its two vtkImplicitPolyDataDistance2
+   * locators (ICP/vtkPolyDataCorrespondenceFilter.cxx:349-366). */
+  int icpx_create(icpx_ctx** out, int device);
+  void icpx_destroy(icpx_ctx* ctx);
+
+  /* Run the context's work on an existing HIP stream (hipStream_t passed as
+   * void*; NULL = the context's own stream). */
+  int icpx_set_stream(icpx_ctx* ctx, void* hip_stream);
+
+  /* Wait for everything queued on the context's stream. */
+  int icpx_synchronize(icpx_ctx* ctx);
+
+  /* Target mesh: nv float points, nt triangles (vertex indices), optional
+   * per-triangle unit normals (used verbatim instead of computed ones).
+   * Builds, on the device, the Morton-ordered wide BVH and the face / edge /
+   * vertex pseudo-normal tables.  Replaces
+   * vtkImplicitPolyDataDistance2::SetInput (ICP/vtkImplicitPolyDataDistance2.cxx:34-62:
+   * triangle filter, BuildLinks, vtkCellLocator::BuildLocator) and the run-time
+   * GetCellEdgeNeighbors / GetPointCells walks of ClosestPointAndNormal
+   * (same file, :433, :475).  Inputs must already be triangles; cell ids
+   * returned later are indices into `tri`. */
+  int icpx_set_target(icpx_ctx* ctx, const float* xyz, int64_t nv, const int32_t* tri, int64_t nt,
+    const float* cell_normals_or_null);
+
+  /* Source points (float, as vtkICP requires: ICP/vtkICP.cxx:145-150) and
+   * optional per-point normals (needed by the symmetric metric; the reference
+   * takes them from vtkPolyDataNormals, ICP/vtkPolyDataCorrespondenceFilter.cxx:457-471). */
+  int icpx_set_source(
+    icpx_ctx* ctx, const float* xyz, int64_t np, const float* normals_or_null);
+
+  /* Restrict this context to shard `rank` of `world` equal contiguous blocks
+   * of the kept source indices {0, step, 2*step, ...}.  Default (0, 1). */
+  int icpx_set_shard(icpx_ctx* ctx, int rank, int world);
+
+  /* Point about which the raw moments are taken (centre of the target's
+   * bounds); identical on every context that holds the same target. */
+  int icpx_get_origin(icpx_ctx* ctx, double origin[3]);
+
+  /* One pass of the correspondence filter fused with the solver's
+   * accumulation: for every kept source index i (i % step == 0, in this
+   * context's shard) transform the point by T in fp64, find the closest point,
+   * cell and pseudo-normal on the target, apply the |d| < max_dist test (and
+   * dot(n_target, n_source) > min_dot when use_source_normals != 0), and add
+   * the accepted row, rounded to float as the reference's outputs are, into
+   * the metric's fp64 sums.  No rows are written.
+   *   sums_host   != NULL: the ICPX_NSUMS sums are copied there (synchronises);
+   *   sums_device != NULL: they are left in that device buffer, stream-ordered,
+   *                        ready for an all-reduce across GPUs.
+   * Replaces Functor/NormalsFunctor::operator() + Reduce
+   * (ICP/vtkPolyDataCorrespondenceFilter.cxx:87-168, 252-341), the three Eigen
+   * copies of vtkICP::InternalUpdate (ICP/vtkICP.cxx:193-216) and the O(n)
+   * loops of the solvers (ICP/icp/point2point.cxx:33-44,
+   * point2plane.cxx:43-84, plane2plane.cxx:41-67). */
+  int icpx_accumulate(icpx_ctx* ctx, int metric, const double T[16], int64_t step,
+    double max_dist, double min_dot, int use_source_normals, double* sums_host,
+    double* sums_device);
+
+  /* The same search, returning the filter's outputs instead of sums: accepted
+   * rows in ascending source-index order, compacted on the device.  Any output
+   * pointer may be NULL.  Buffers must hold ceil(np/step) rows (this shard's
+   * share of them when sharded).  Replaces
+   * vtkPolyDataCorrespondenceFilter::RequestData's two output ports
+   * (ICP/vtkPolyDataCorrespondenceFilter.cxx:397-547); cell, dist and
+   * src_index are extra (the reference keeps them local, :363,:375). */
+  int icpx_correspond(icpx_ctx* ctx, const double T[16], int64_t step, double max_dist,
+    double min_dot, int use_source_normals, float* origin, float* origin_normal, float* closest,
+    float* normal, int32_t* cell, double* dist, int64_t* src_index, int64_t* n_out);
+
+  /* Host-side solve of one iteration from (all-reduced) sums: 3x3 SVD for
+   * point-to-point (ICP/icp/point2point.cxx:45-58), 6x6 LDL^T + Euler XYZ for
+   * point-to-plane (ICP/icp/point2plane.cxx:88-106), 6x6 LDL^T + Rodrigues
+   * half-rotation for the symmetric metric (ICP/icp/plane2plane.cxx:68-92).
+   * M is the incremental transform; n_out / mean_dist_out (optional) return
+   * the accepted count and the mean |s - t|.  ICPX_E_FEW (M = identity) when
+   * fewer than 3 (point-to-point) or 6 rows were accepted. */
+  int icpx_solve(int metric, const double sums[ICPX_NSUMS], const double origin[3], double M[16],
+    int64_t* n_out, double* mean_dist_out);
+
+  /* Parameters of a whole registration; defaults as vtkICP's constructor
+   * (ICP/vtkICP.cxx:27-40) with MaximumNumberOfLandmarks = 200 as documented
+   * in ICP/vtkICP.h:52-59 (the reference leaves it uninitialised). */
+  typedef struct icpx_params
+  {
+    int metric;
+    int max_iterations;
+    int64_t max_landmarks;
+    double max_distance;
+    int check_mean_distance;
+    double max_mean_distance;
+    double min_normal_dot;
+  } icpx_params;
+  void icpx_default_params(icpx_params* p);
+
+  /* Optional hook called once per iteration on the host copy of the sums,
+   * between the search and the solve; a multi-process driver sums them over
+   * ranks there (in place).  Return non-zero to abort the run. */
+  typedef int (*icpx_allreduce_fn)(double* sums, int n, void* user);
+  int icpx_set_allreduce(icpx_ctx* ctx, icpx_allreduce_fn fn, void* user);
+
+  /* status values of icpx_run */
+#define ICPX_RUN_MAX_ITERATIONS 0 /* ran MaximumNumberOfIterations */
+#define ICPX_RUN_CONVERGED 1      /* mean distance <= MaximumMeanDistance */
+#define ICPX_RUN_TOO_FEW 2        /* too few correspondences; transform kept */
+
+  /* The whole loop of vtkICP::InternalUpdate (ICP/vtkICP.cxx:189-246):
+   * search, optional mean-distance early-out, solve, T <- M*T, repeated.
+   * T_out is the accumulated transform (what vtkICP copies into this->Matrix). */
+  int icpx_run(icpx_ctx* ctx, const icpx_params* p, double T_out[16], int* iterations_out,
+    double* mean_distance_out, int* status_out);
+
+  /* Wall-clock seconds the last icpx_set_target spent building the BVH and
+   * tables on the device (for reporting; not part of the reference surface). */
+  double icpx_last_build_seconds(icpx_ctx* ctx);
+
+  /* Search-kernel variant: lanes that cooperate on one query (4, 8, 16, 32 or 64 =
+   * one wavefront per query); 0 = choose from the number of queries. Changing
+   * it rebuilds the tree on the next icpx_set_target. */
+  int icpx_set_group_width(icpx_ctx* ctx, int lanes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICPX_H */

@@ -1,0 +1,933 @@
+// icpx.hip — the C ABI of libicpx (include/icpx.h) over the gfx950 kernels in
+// bvh.hpp / tables.hpp / query.hpp / prims.hpp.  Host code here only validates
+// shapes, owns device memory and orders launches on one HIP stream; all
+// per-point arithmetic runs on the GPU and the only host arithmetic is the O(1)
+// solve in solve.cpp.
+#include "../../include/icpx.h"
+#include "bvh.hpp"
+#include "prims.hpp"
+#include "query.hpp"
+#include "tables.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <new>
+
+using namespace icpx;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do                                                                                              \
+  {                                                                                               \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(ICPX_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,    \
+        __LINE__);                                                                                \
+  } while (0)
+
+#define LAUNCHCHK() HIPCHK(hipGetLastError())
+
+static const int kWidths[5] = { 4, 8, 16, 32, 64 };
+
+struct Tree
+{
+  TreeLevels lv;
+  float* nodes = nullptr;
+  bool built = false;
+};
+
+struct icpx_ctx
+{
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+
+  // target
+  int64_t nv = 0, nt = 0;
+  float* d_xyz = nullptr;
+  int32_t* d_tri = nullptr;
+  float* d_tverts = nullptr;
+  int32_t* d_tid = nullptr;
+  float *d_fn = nullptr, *d_en = nullptr, *d_vn = nullptr;
+  Box3 box;
+  double origin[3] = { 0, 0, 0 };
+  Tree trees[5];
+  double build_seconds = 0.0;
+
+  // source
+  int64_t np = 0;
+  float* d_src = nullptr;
+  float* d_srcn = nullptr;
+  uint64_t src_version = 0;
+  int rank = 0, world = 1;
+
+  // queries prepared for (step, shard, source version)
+  int64_t prep_step = -1;
+  int prep_rank = -1, prep_world = -1;
+  uint64_t prep_version = 0;
+  int64_t nq = 0, k0 = 0, q_cap = 0;
+  float* d_qpos = nullptr;
+  float* d_qsn = nullptr;
+  int32_t* d_qk = nullptr;
+  int32_t* d_hint = nullptr;
+  bool hint_valid = false;
+
+  // per-pass scratch
+  double* d_partials = nullptr;
+  double* d_sums = nullptr;
+  double* h_sums = nullptr; // pinned
+  int max_blocks = 1024;
+
+  // row outputs (icpx_correspond)
+  int64_t rows_cap = 0;
+  float *r_origin = nullptr, *r_onormal = nullptr, *r_closest = nullptr, *r_normal = nullptr;
+  int32_t* r_cell = nullptr;
+  double* r_dist = nullptr;
+  uint32_t *r_flag = nullptr, *r_pos = nullptr, *r_scan = nullptr;
+  float *c_origin = nullptr, *c_onormal = nullptr, *c_closest = nullptr, *c_normal = nullptr;
+  int32_t* c_cell = nullptr;
+  double* c_dist = nullptr;
+  int64_t* c_index = nullptr;
+
+  int group_width = 0;
+  icpx_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+};
+
+template <typename T>
+static int dev_alloc(T** p, int64_t count)
+{
+  if (*p)
+  {
+    (void)hipFree(*p);
+    *p = nullptr;
+  }
+  if (count <= 0)
+    count = 1;
+  hipError_t e = hipMalloc((void**)p, sizeof(T) * (size_t)count);
+  if (e != hipSuccess)
+  {
+    *p = nullptr;
+    return fail(ICPX_E_NOMEM, "hipMalloc of %lld bytes failed: %s",
+      (long long)(sizeof(T) * (size_t)count), hipGetErrorString(e));
+  }
+  return ICPX_OK;
+}
+template <typename T>
+static void dev_free(T** p)
+{
+  if (*p)
+    (void)hipFree(*p);
+  *p = nullptr;
+}
+#define ALLOC(ptr, count)                                                                         \
+  do                                                                                              \
+  {                                                                                               \
+    int rc_ = dev_alloc(&(ptr), (count));                                                         \
+    if (rc_)                                                                                      \
+      return rc_;                                                                                 \
+  } while (0)
+
+static inline unsigned nblk(int64_t n, int threads)
+{
+  return (unsigned)((n + threads - 1) / threads);
+}
+
+static void free_target(icpx_ctx* c)
+{
+  dev_free(&c->d_xyz);
+  dev_free(&c->d_tri);
+  dev_free(&c->d_tverts);
+  dev_free(&c->d_tid);
+  dev_free(&c->d_fn);
+  dev_free(&c->d_en);
+  dev_free(&c->d_vn);
+  for (auto& t : c->trees)
+  {
+    dev_free(&t.nodes);
+    t.built = false;
+  }
+  c->nv = c->nt = 0;
+}
+static void free_queries(icpx_ctx* c)
+{
+  dev_free(&c->d_qpos);
+  dev_free(&c->d_qsn);
+  dev_free(&c->d_qk);
+  dev_free(&c->d_hint);
+  c->q_cap = 0;
+  c->prep_step = -1;
+}
+static void free_rows(icpx_ctx* c)
+{
+  dev_free(&c->r_origin);
+  dev_free(&c->r_onormal);
+  dev_free(&c->r_closest);
+  dev_free(&c->r_normal);
+  dev_free(&c->r_cell);
+  dev_free(&c->r_dist);
+  dev_free(&c->r_flag);
+  dev_free(&c->r_pos);
+  dev_free(&c->r_scan);
+  dev_free(&c->c_origin);
+  dev_free(&c->c_onormal);
+  dev_free(&c->c_closest);
+  dev_free(&c->c_normal);
+  dev_free(&c->c_cell);
+  dev_free(&c->c_dist);
+  dev_free(&c->c_index);
+  c->rows_cap = 0;
+}
+
+extern "C" const char* icpx_last_error(void)
+{
+  return g_err;
+}
+
+extern "C" int icpx_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+extern "C" int icpx_create(icpx_ctx** out, int device)
+{
+  if (!out)
+    return fail(ICPX_E_INVALID, "icpx_create: out is null");
+  *out = nullptr;
+  int n = icpx_device_count();
+  if (device < 0 || device >= n)
+    return fail(ICPX_E_INVALID, "icpx_create: device %d not available (%d visible)", device, n);
+  HIPCHK(hipSetDevice(device));
+  icpx_ctx* c = new (std::nothrow) icpx_ctx();
+  if (!c)
+    return fail(ICPX_E_NOMEM, "icpx_create: out of host memory");
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess)
+  {
+    delete c;
+    return fail(ICPX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+  }
+  c->stream = c->own_stream;
+  int rc = dev_alloc(&c->d_partials, (int64_t)c->max_blocks * ICPX_NSUMS);
+  if (!rc)
+    rc = dev_alloc(&c->d_sums, ICPX_NSUMS);
+  if (!rc && hipHostMalloc((void**)&c->h_sums, sizeof(double) * ICPX_NSUMS) != hipSuccess)
+    rc = fail(ICPX_E_NOMEM, "hipHostMalloc failed");
+  if (rc)
+  {
+    icpx_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return ICPX_OK;
+}
+
+extern "C" void icpx_destroy(icpx_ctx* c)
+{
+  if (!c)
+    return;
+  (void)hipSetDevice(c->device);
+  if (c->stream)
+    (void)hipStreamSynchronize(c->stream);
+  free_target(c);
+  free_queries(c);
+  free_rows(c);
+  dev_free(&c->d_src);
+  dev_free(&c->d_srcn);
+  dev_free(&c->d_partials);
+  dev_free(&c->d_sums);
+  if (c->h_sums)
+    (void)hipHostFree(c->h_sums);
+  if (c->own_stream)
+    (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+extern "C" int icpx_set_stream(icpx_ctx* c, void* s)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_synchronize(icpx_ctx* c)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_group_width(icpx_ctx* c, int lanes)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  if (lanes != 0 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64)
+    return fail(ICPX_E_INVALID, "group width must be 0, 4, 8, 16, 32 or 64 (got %d)", lanes);
+  c->group_width = lanes;
+  return ICPX_OK;
+}
+
+extern "C" double icpx_last_build_seconds(icpx_ctx* c)
+{
+  return c ? c->build_seconds : 0.0;
+}
+
+extern "C" int icpx_get_origin(icpx_ctx* c, double origin[3])
+{
+  if (!c || !origin)
+    return fail(ICPX_E_INVALID, "null argument");
+  if (c->nt == 0)
+    return fail(ICPX_E_INVALID, "icpx_get_origin: no target set");
+  for (int i = 0; i < 3; i++)
+    origin[i] = c->origin[i];
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_allreduce(icpx_ctx* c, icpx_allreduce_fn fn, void* user)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  c->allreduce = fn;
+  c->allreduce_user = user;
+  return ICPX_OK;
+}
+
+extern "C" void icpx_default_params(icpx_params* p)
+{
+  if (!p)
+    return;
+  p->metric = ICPX_METRIC_POINT_TO_PLANE;
+  p->max_iterations = 50;
+  p->max_landmarks = 200;
+  p->max_distance = 10.0;
+  p->check_mean_distance = 0;
+  p->max_mean_distance = 0.01;
+  p->min_normal_dot = 0.0;
+}
+
+// ------------------------------------------------------------------ target ----
+extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const int32_t* tri,
+  int64_t nt, const float* cell_normals)
+{
+  if (!c || !xyz || !tri)
+    return fail(ICPX_E_INVALID, "icpx_set_target: null argument");
+  if (nv <= 0 || nt <= 0)
+    return fail(ICPX_E_INVALID, "icpx_set_target: empty target (%lld points, %lld triangles)",
+      (long long)nv, (long long)nt);
+  if (nv >= (1ll << 31) || nt >= (1ll << 28) * 4)
+    return fail(ICPX_E_INVALID, "icpx_set_target: target too large");
+  for (int64_t i = 0; i < 3 * nt; i++)
+    if (tri[i] < 0 || tri[i] >= nv)
+      return fail(ICPX_E_INVALID, "icpx_set_target: triangle %lld refers to point %d of %lld",
+        (long long)(i / 3), tri[i], (long long)nv);
+  float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+  for (int64_t i = 0; i < nv; i++)
+    for (int a = 0; a < 3; a++)
+    {
+      float v = xyz[3 * i + a];
+      if (!std::isfinite(v))
+        return fail(ICPX_E_INVALID, "icpx_set_target: point %lld is not finite", (long long)i);
+      lo[a] = v < lo[a] ? v : lo[a];
+      hi[a] = v > hi[a] ? v : hi[a];
+    }
+
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  auto t0 = std::chrono::steady_clock::now();
+  free_target(c);
+  c->hint_valid = false;
+  c->prep_step = -1; // query order depends on the target's bounds
+  hipStream_t st = c->stream;
+  for (int a = 0; a < 3; a++)
+  {
+    c->box.lo[a] = lo[a];
+    float ext = hi[a] - lo[a];
+    c->box.inv[a] = ext > 0.f ? 1.f / ext : 0.f;
+    c->origin[a] = 0.5 * ((double)lo[a] + (double)hi[a]);
+  }
+
+  ALLOC(c->d_xyz, 3 * nv);
+  ALLOC(c->d_tri, 3 * nt);
+  HIPCHK(hipMemcpyAsync(c->d_xyz, xyz, sizeof(float) * 3 * nv, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->d_tri, tri, sizeof(int32_t) * 3 * nt, hipMemcpyHostToDevice, st));
+
+  // K1/K2: Morton order of the triangles
+  uint64_t *k0 = nullptr, *k1 = nullptr;
+  uint32_t *v0 = nullptr, *v1 = nullptr, *scr = nullptr;
+  int rc = dev_alloc(&k0, nt);
+  if (!rc)
+    rc = dev_alloc(&k1, nt);
+  if (!rc)
+    rc = dev_alloc(&v0, nt);
+  if (!rc)
+    rc = dev_alloc(&v1, nt);
+  if (!rc)
+    rc = dev_alloc(&scr, rs_scratch_words(nt));
+  if (!rc)
+    rc = dev_alloc(&c->d_tverts, 9 * nt);
+  if (!rc)
+    rc = dev_alloc(&c->d_tid, nt);
+  auto drop_sort = [&]() {
+    dev_free(&k0);
+    dev_free(&k1);
+    dev_free(&v0);
+    dev_free(&v1);
+    dev_free(&scr);
+  };
+  if (rc)
+  {
+    drop_sort();
+    return rc;
+  }
+  k_morton_tris<<<nblk(nt, 256), 256, 0, st>>>(c->d_xyz, c->d_tri, nt, c->box, k0, v0);
+  int which = radix_sort_pairs(k0, v0, k1, v1, nt, 63, scr, st);
+  k_gather_tris<<<nblk(nt, 256), 256, 0, st>>>(
+    c->d_xyz, c->d_tri, which ? v1 : v0, nt, c->d_tverts, c->d_tid);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  drop_sort();
+  if (e != hipSuccess)
+    return fail(ICPX_E_HIP, "target ordering failed: %s", hipGetErrorString(e));
+
+  // K5: links and pseudo-normal tables
+  double* fn64 = nullptr;
+  uint32_t *voff = nullptr, *cursor = nullptr, *sscr = nullptr;
+  int32_t* vcell = nullptr;
+  float* d_cn = nullptr;
+  auto drop_tab = [&]() {
+    dev_free(&fn64);
+    dev_free(&voff);
+    dev_free(&cursor);
+    dev_free(&sscr);
+    dev_free(&vcell);
+    dev_free(&d_cn);
+  };
+  rc = dev_alloc(&fn64, 3 * nt);
+  if (!rc)
+    rc = dev_alloc(&voff, nv + 1);
+  if (!rc)
+    rc = dev_alloc(&cursor, nv + 1);
+  if (!rc)
+    rc = dev_alloc(&sscr, scan_scratch_words(nv + 1));
+  if (!rc)
+    rc = dev_alloc(&vcell, 3 * nt);
+  if (!rc && cell_normals)
+    rc = dev_alloc(&d_cn, 3 * nt);
+  if (!rc)
+    rc = dev_alloc(&c->d_fn, 3 * nt);
+  if (!rc)
+    rc = dev_alloc(&c->d_en, 9 * nt);
+  if (!rc)
+    rc = dev_alloc(&c->d_vn, 3 * nv);
+  if (rc)
+  {
+    drop_tab();
+    return rc;
+  }
+  if (cell_normals)
+    (void)hipMemcpyAsync(d_cn, cell_normals, sizeof(float) * 3 * nt, hipMemcpyHostToDevice, st);
+  k_face_normals<<<nblk(nt, 256), 256, 0, st>>>(c->d_xyz, c->d_tri, d_cn, nt, fn64, c->d_fn);
+  (void)hipMemsetAsync(voff, 0, sizeof(uint32_t) * (nv + 1), st);
+  (void)hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (nv + 1), st);
+  k_valence<<<nblk(3 * nt, 256), 256, 0, st>>>(c->d_tri, 3 * nt, voff);
+  exclusive_scan(voff, voff, nv + 1, sscr, st);
+  k_fill_links<<<nblk(3 * nt, 256), 256, 0, st>>>(c->d_tri, 3 * nt, voff, cursor, vcell);
+  k_sort_links<<<nblk(nv, 256), 256, 0, st>>>(voff, nv, vcell);
+  k_vertex_normals<<<nblk(nv, 256), 256, 0, st>>>(
+    c->d_xyz, c->d_tri, voff, vcell, fn64, nv, c->d_vn);
+  k_edge_normals<<<nblk(3 * nt, 256), 256, 0, st>>>(c->d_tri, voff, vcell, fn64, nt, c->d_en);
+  e = hipGetLastError();
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  drop_tab();
+  if (e != hipSuccess)
+    return fail(ICPX_E_HIP, "normal tables failed: %s", hipGetErrorString(e));
+
+  c->nv = nv;
+  c->nt = nt;
+  c->build_seconds =
+    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return ICPX_OK;
+}
+
+// K3: the box hierarchy for one fan-out, built on first use.
+static int ensure_tree(icpx_ctx* c, int G)
+{
+  int slot = -1;
+  for (int i = 0; i < 5; i++)
+    if (kWidths[i] == G)
+      slot = i;
+  if (slot < 0)
+    return fail(ICPX_E_INVALID, "bad group width %d", G);
+  Tree& t = c->trees[slot];
+  if (t.built)
+    return ICPX_OK;
+  t.lv = make_levels(c->nt, G);
+  int maxlev = (G == 4) ? SearchCfg<4>::LEVELS
+                        : (G == 8) ? SearchCfg<8>::LEVELS
+                                   : (G == 16) ? SearchCfg<16>::LEVELS
+                                               : (G == 32) ? SearchCfg<32>::LEVELS
+                                                           : SearchCfg<64>::LEVELS;
+  if (t.lv.cnt[t.lv.nlev] != 1 || t.lv.nlev > maxlev || t.lv.cnt[0] >= (1 << 28))
+    return fail(ICPX_E_INVALID, "target too large for fan-out %d", G);
+  ALLOC(t.nodes, t.lv.total_floats);
+  hipStream_t st = c->stream;
+  k_build_level1<<<nblk((int64_t)t.lv.cnt[1] * G, 256), 256, 0, st>>>(
+    c->d_tverts, c->nt, t.lv, t.nodes);
+  for (int L = 2; L <= t.lv.nlev; L++)
+    k_build_level<<<nblk((int64_t)t.lv.cnt[L] * G, 256), 256, 0, st>>>(L, t.lv, t.nodes);
+  LAUNCHCHK();
+  t.built = true;
+  return ICPX_OK;
+}
+
+// ------------------------------------------------------------------ source ----
+extern "C" int icpx_set_source(icpx_ctx* c, const float* xyz, int64_t np, const float* normals)
+{
+  if (!c || !xyz)
+    return fail(ICPX_E_INVALID, "icpx_set_source: null argument");
+  if (np <= 0 || np >= (1ll << 31))
+    return fail(ICPX_E_INVALID, "icpx_set_source: bad point count %lld", (long long)np);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  ALLOC(c->d_src, 3 * np);
+  HIPCHK(hipMemcpyAsync(c->d_src, xyz, sizeof(float) * 3 * np, hipMemcpyHostToDevice, c->stream));
+  if (normals)
+  {
+    ALLOC(c->d_srcn, 3 * np);
+    HIPCHK(hipMemcpyAsync(
+      c->d_srcn, normals, sizeof(float) * 3 * np, hipMemcpyHostToDevice, c->stream));
+  }
+  else
+    dev_free(&c->d_srcn);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->np = np;
+  c->src_version++;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_shard(icpx_ctx* c, int rank, int world)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  if (world < 1 || rank < 0 || rank >= world)
+    return fail(ICPX_E_INVALID, "icpx_set_shard: bad shard %d of %d", rank, world);
+  c->rank = rank;
+  c->world = world;
+  return ICPX_OK;
+}
+
+// Kept points of this shard, gathered in Morton order (relative to the target's bounds).
+static int prepare_queries(icpx_ctx* c, int64_t step)
+{
+  if (c->nt == 0)
+    return fail(ICPX_E_INVALID, "no target set");
+  if (c->np == 0)
+    return fail(ICPX_E_INVALID, "no source set");
+  if (step < 1)
+    return fail(ICPX_E_INVALID, "step must be >= 1");
+  if (c->prep_step == step && c->prep_rank == c->rank && c->prep_world == c->world &&
+    c->prep_version == c->src_version)
+    return ICPX_OK;
+  const int64_t nk = (c->np + step - 1) / step;
+  const int64_t k0 = nk * c->rank / c->world, k1 = nk * (c->rank + 1) / c->world;
+  const int64_t nq = k1 - k0;
+  hipStream_t st = c->stream;
+  if (nq > c->q_cap)
+  {
+    ALLOC(c->d_qpos, 3 * nq);
+    ALLOC(c->d_qsn, 3 * nq);
+    ALLOC(c->d_qk, nq);
+    ALLOC(c->d_hint, nq);
+    c->q_cap = nq;
+  }
+  if (nq > 0)
+  {
+    uint64_t *ka = nullptr, *kb = nullptr;
+    uint32_t *va = nullptr, *vb = nullptr, *scr = nullptr;
+    int rc = dev_alloc(&ka, nq);
+    if (!rc)
+      rc = dev_alloc(&kb, nq);
+    if (!rc)
+      rc = dev_alloc(&va, nq);
+    if (!rc)
+      rc = dev_alloc(&vb, nq);
+    if (!rc)
+      rc = dev_alloc(&scr, rs_scratch_words(nq));
+    hipError_t e = hipSuccess;
+    if (!rc)
+    {
+      k_morton_points<<<nblk(nq, 256), 256, 0, st>>>(c->d_src, k0, step, nq, c->box, ka, va);
+      int which = radix_sort_pairs(ka, va, kb, vb, nq, 63, scr, st);
+      k_gather_queries<<<nblk(nq, 256), 256, 0, st>>>(c->d_src, c->d_srcn, which ? vb : va, k0,
+        step, nq, c->d_qpos, c->d_qsn, c->d_qk, c->d_hint);
+      e = hipGetLastError();
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    }
+    dev_free(&ka);
+    dev_free(&kb);
+    dev_free(&va);
+    dev_free(&vb);
+    dev_free(&scr);
+    if (rc)
+      return rc;
+    if (e != hipSuccess)
+      return fail(ICPX_E_HIP, "query ordering failed: %s", hipGetErrorString(e));
+  }
+  c->nq = nq;
+  c->k0 = k0;
+  c->prep_step = step;
+  c->prep_rank = c->rank;
+  c->prep_world = c->world;
+  c->prep_version = c->src_version;
+  c->hint_valid = false;
+  return ICPX_OK;
+}
+
+static int pick_width(const icpx_ctx* c)
+{
+  if (c->group_width)
+    return c->group_width;
+  // few queries: spend a whole wavefront on each; many: 8 queries per wavefront
+  if (c->nq <= 16384)
+    return 64;
+  if (c->nq <= 131072)
+    return 16;
+  return 8;
+}
+
+static void fill_xf(Xf& x, const double T[16])
+{
+  for (int i = 0; i < 12; i++)
+    x.m[i] = T[i];
+}
+
+static int run_search(icpx_ctx* c, const double T[16])
+{
+  const int G = pick_width(c);
+  int rc = ensure_tree(c, G);
+  if (rc)
+    return rc;
+  int slot = 0;
+  for (int i = 0; i < 5; i++)
+    if (kWidths[i] == G)
+      slot = i;
+  const Tree& t = c->trees[slot];
+  SearchArgs a;
+  a.qpos = c->d_qpos;
+  a.nq = c->nq;
+  fill_xf(a.T, T);
+  a.nodes = t.nodes;
+  a.lv = t.lv;
+  a.tverts = c->d_tverts;
+  a.tid = c->d_tid;
+  a.nt = c->nt;
+  a.hint = c->d_hint;
+  a.use_hint = c->hint_valid ? 1 : 0;
+  const unsigned grid = nblk(c->nq, 256 / G);
+  hipStream_t st = c->stream;
+  switch (G)
+  {
+    case 4:
+      k_search<4><<<grid, 256, 0, st>>>(a);
+      break;
+    case 8:
+      k_search<8><<<grid, 256, 0, st>>>(a);
+      break;
+    case 16:
+      k_search<16><<<grid, 256, 0, st>>>(a);
+      break;
+    case 32:
+      k_search<32><<<grid, 256, 0, st>>>(a);
+      break;
+    default:
+      k_search<64><<<grid, 256, 0, st>>>(a);
+      break;
+  }
+  LAUNCHCHK();
+  c->hint_valid = true;
+  return ICPX_OK;
+}
+
+static void fill_final(icpx_ctx* c, FinalArgs& f, const double T[16], double max_dist,
+  double min_dot, int use_sn, bool want_sn)
+{
+  std::memset(&f, 0, sizeof(f));
+  f.qpos = c->d_qpos;
+  f.qsn = want_sn ? c->d_qsn : nullptr;
+  f.qk = c->d_qk;
+  f.nq = c->nq;
+  fill_xf(f.T, T);
+  for (int i = 0; i < 3; i++)
+    f.origin[i] = c->origin[i];
+  f.tverts = c->d_tverts;
+  f.tid = c->d_tid;
+  f.tri = c->d_tri;
+  f.fnorm = c->d_fn;
+  f.enorm = c->d_en;
+  f.vnorm = c->d_vn;
+  f.hint = c->d_hint;
+  f.max_dist = max_dist;
+  f.min_dot = min_dot;
+  f.use_sn = use_sn;
+  f.partials = c->d_partials;
+}
+
+static int check_call(icpx_ctx* c, const double* T, int metric, int use_sn)
+{
+  if (!c || !T)
+    return fail(ICPX_E_INVALID, "null argument");
+  if (metric < 0 || metric > 2)
+    return fail(ICPX_E_INVALID, "unknown metric %d", metric);
+  if ((metric == ICPX_METRIC_PLANE_TO_PLANE || use_sn) && !c->d_srcn)
+    return fail(ICPX_E_INVALID, "Plane to plane metric requires source normals");
+  for (int i = 0; i < 16; i++)
+    if (!std::isfinite(T[i]))
+      return fail(ICPX_E_INVALID, "transform is not finite");
+  return ICPX_OK;
+}
+
+extern "C" int icpx_accumulate(icpx_ctx* c, int metric, const double T[16], int64_t step,
+  double max_dist, double min_dot, int use_sn, double* sums_host, double* sums_device)
+{
+  int rc = check_call(c, T, metric, use_sn);
+  if (rc)
+    return rc;
+  HIPCHK(hipSetDevice(c->device));
+  rc = prepare_queries(c, step);
+  if (rc)
+    return rc;
+  hipStream_t st = c->stream;
+  double* dst = sums_device ? sums_device : c->d_sums;
+  if (c->nq == 0)
+  {
+    HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * ICPX_NSUMS, st));
+  }
+  else
+  {
+    rc = run_search(c, T);
+    if (rc)
+      return rc;
+    FinalArgs f;
+    fill_final(c, f, T, max_dist, min_dot, use_sn,
+      use_sn || metric == ICPX_METRIC_PLANE_TO_PLANE);
+    int grid = (int)nblk(c->nq, FIN_THREADS);
+    if (grid > c->max_blocks)
+      grid = c->max_blocks;
+    if (metric == 0)
+      k_finalize<0, false><<<grid, FIN_THREADS, 0, st>>>(f);
+    else if (metric == 1)
+      k_finalize<1, false><<<grid, FIN_THREADS, 0, st>>>(f);
+    else
+      k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
+    k_reduce_partials<<<1, 64, 0, st>>>(c->d_partials, grid, dst);
+    LAUNCHCHK();
+  }
+  if (sums_host)
+  {
+    HIPCHK(hipMemcpyAsync(
+      c->h_sums, dst, sizeof(double) * ICPX_NSUMS, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::memcpy(sums_host, c->h_sums, sizeof(double) * ICPX_NSUMS);
+  }
+  return ICPX_OK;
+}
+
+extern "C" int icpx_correspond(icpx_ctx* c, const double T[16], int64_t step, double max_dist,
+  double min_dot, int use_sn, float* origin, float* origin_normal, float* closest, float* normal,
+  int32_t* cell, double* dist, int64_t* src_index, int64_t* n_out)
+{
+  int rc = check_call(c, T, 0, use_sn);
+  if (rc)
+    return rc;
+  if (!n_out)
+    return fail(ICPX_E_INVALID, "icpx_correspond: n_out is null");
+  *n_out = 0;
+  HIPCHK(hipSetDevice(c->device));
+  rc = prepare_queries(c, step);
+  if (rc)
+    return rc;
+  const int64_t nq = c->nq;
+  if (nq == 0)
+    return ICPX_OK;
+  hipStream_t st = c->stream;
+  if (nq > c->rows_cap)
+  {
+    free_rows(c);
+    ALLOC(c->r_origin, 3 * nq);
+    ALLOC(c->r_onormal, 3 * nq);
+    ALLOC(c->r_closest, 3 * nq);
+    ALLOC(c->r_normal, 3 * nq);
+    ALLOC(c->r_cell, nq);
+    ALLOC(c->r_dist, nq);
+    ALLOC(c->r_flag, nq + 1);
+    ALLOC(c->r_pos, nq + 1);
+    ALLOC(c->r_scan, scan_scratch_words(nq + 1));
+    ALLOC(c->c_origin, 3 * nq);
+    ALLOC(c->c_onormal, 3 * nq);
+    ALLOC(c->c_closest, 3 * nq);
+    ALLOC(c->c_normal, 3 * nq);
+    ALLOC(c->c_cell, nq);
+    ALLOC(c->c_dist, nq);
+    ALLOC(c->c_index, nq);
+    c->rows_cap = nq;
+  }
+  rc = run_search(c, T);
+  if (rc)
+    return rc;
+  FinalArgs f;
+  fill_final(c, f, T, max_dist, min_dot, use_sn, use_sn != 0);
+  f.o_origin = c->r_origin;
+  f.o_onormal = use_sn ? c->r_onormal : nullptr;
+  f.o_closest = c->r_closest;
+  f.o_normal = c->r_normal;
+  f.o_cell = c->r_cell;
+  f.o_dist = c->r_dist;
+  f.o_flag = c->r_flag;
+  int grid = (int)nblk(nq, FIN_THREADS);
+  if (grid > c->max_blocks)
+    grid = c->max_blocks;
+  HIPCHK(hipMemsetAsync(c->r_flag + nq, 0, sizeof(uint32_t), st));
+  k_finalize<0, true><<<grid, FIN_THREADS, 0, st>>>(f);
+  exclusive_scan(c->r_flag, c->r_pos, nq + 1, c->r_scan, st);
+  CompactArgs ca;
+  ca.nq = nq;
+  ca.k0 = c->k0;
+  ca.step = step;
+  ca.flag = c->r_flag;
+  ca.pos = c->r_pos;
+  ca.origin = c->r_origin;
+  ca.onormal = c->r_onormal;
+  ca.closest = c->r_closest;
+  ca.normal = c->r_normal;
+  ca.cell = c->r_cell;
+  ca.dist = c->r_dist;
+  ca.d_origin = c->c_origin;
+  ca.d_onormal = use_sn ? c->c_onormal : nullptr;
+  ca.d_closest = c->c_closest;
+  ca.d_normal = c->c_normal;
+  ca.d_cell = c->c_cell;
+  ca.d_dist = c->c_dist;
+  ca.d_index = c->c_index;
+  k_compact_rows<<<nblk(nq, 256), 256, 0, st>>>(ca);
+  LAUNCHCHK();
+  uint32_t n = 0;
+  HIPCHK(hipMemcpyAsync(&n, c->r_pos + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  auto back = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    if (!dst || !bytes)
+      return hipSuccess;
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+  };
+  HIPCHK(back(origin, c->c_origin, sizeof(float) * 3 * n));
+  if (use_sn)
+    HIPCHK(back(origin_normal, c->c_onormal, sizeof(float) * 3 * n));
+  HIPCHK(back(closest, c->c_closest, sizeof(float) * 3 * n));
+  HIPCHK(back(normal, c->c_normal, sizeof(float) * 3 * n));
+  HIPCHK(back(cell, c->c_cell, sizeof(int32_t) * n));
+  HIPCHK(back(dist, c->c_dist, sizeof(double) * n));
+  HIPCHK(back(src_index, c->c_index, sizeof(int64_t) * n));
+  HIPCHK(hipStreamSynchronize(st));
+  *n_out = n;
+  return ICPX_OK;
+}
+
+// ---------------------------------------------------------------- the loop ----
+extern "C" int icpx_run(icpx_ctx* c, const icpx_params* p, double T_out[16], int* iterations_out,
+  double* mean_distance_out, int* status_out)
+{
+  if (!c || !p || !T_out)
+    return fail(ICPX_E_INVALID, "icpx_run: null argument");
+  if (c->nt == 0)
+    return fail(ICPX_E_INVALID, "Can't execute with nullptr or empty target");
+  if (c->np == 0)
+    return fail(ICPX_E_INVALID, "Can't execute with nullptr or empty input");
+  if (p->metric < 0 || p->metric > 2)
+    return fail(ICPX_E_INVALID, "unknown metric %d", p->metric);
+  if (p->metric == ICPX_METRIC_PLANE_TO_PLANE && !c->d_srcn)
+    return fail(ICPX_E_INVALID, "Plane to plane metric requires source normals");
+  if (p->max_landmarks < 1)
+    return fail(ICPX_E_INVALID, "max_landmarks must be positive");
+  double T[16];
+  for (int i = 0; i < 16; i++)
+    T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  int64_t step = 1;
+  if (c->np > p->max_landmarks)
+    step = c->np / p->max_landmarks; // vtkPolyDataCorrespondenceFilter.cxx:473-477
+  const int use_sn = p->metric == ICPX_METRIC_PLANE_TO_PLANE ? 1 : 0;
+  int iters = 0, status = ICPX_RUN_MAX_ITERATIONS;
+  double mean = 0.0;
+  double sums[ICPX_NSUMS];
+  for (int it = 0; it < p->max_iterations; it++)
+  {
+    int rc = icpx_accumulate(
+      c, p->metric, T, step, p->max_distance, p->min_normal_dot, use_sn, sums, nullptr);
+    if (rc)
+      return rc;
+    if (c->allreduce && c->allreduce(sums, ICPX_NSUMS, c->allreduce_user))
+      return fail(ICPX_E_INVALID, "all-reduce hook reported a failure");
+    double M[16];
+    int64_t n = 0;
+    double md = 0.0;
+    rc = icpx_solve(p->metric, sums, c->origin, M, &n, &md);
+    mean = md;
+    if (p->check_mean_distance)
+    {
+      if (n > 0 && mean <= p->max_mean_distance)
+      {
+        status = ICPX_RUN_CONVERGED;
+        break;
+      }
+    }
+    if (rc == ICPX_E_FEW)
+    {
+      status = ICPX_RUN_TOO_FEW;
+      break;
+    }
+    if (rc)
+      return rc;
+    iters++;
+    double R[16];
+    for (int r = 0; r < 4; r++)
+      for (int k = 0; k < 4; k++)
+      {
+        double acc = 0.0;
+        for (int j = 0; j < 4; j++)
+          acc += M[4 * r + j] * T[4 * j + k];
+        R[4 * r + k] = acc;
+      }
+    std::memcpy(T, R, sizeof(R));
+  }
+  std::memcpy(T_out, T, sizeof(T));
+  if (iterations_out)
+    *iterations_out = iters;
+  if (mean_distance_out)
+    *mean_distance_out = mean;
+  if (status_out)
+    *status_out = status;
+  return ICPX_OK;
+}

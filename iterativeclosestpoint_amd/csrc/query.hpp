@@ -1,0 +1,524 @@
+// query.hpp — the per-iteration kernels.
+//
+//  k_search<G>    closest triangle for every kept source point: G lanes share
+//                 one query, walk the G-ary box hierarchy with a stack in LDS
+//                 (nearest child on top), and test the G triangles of a leaf
+//                 in parallel with the exact fp64 point/triangle routine.
+//                 G = 64 is one wavefront per query.  Replaces
+//                 vtkCellLocator::FindClosestPoint as called from
+//                 ICP/vtkImplicitPolyDataDistance2.cxx:375.
+//  k_finalize<..> one thread per query: closest point, barycentric
+//                 classification, pseudo-normal, thresholds, then either the
+//                 metric's fp64 partial sums (wave shuffles -> LDS -> one
+//                 partial per block) or the filter's output rows.  Replaces
+//                 the rest of ClosestPointAndNormal (:379-527), the functor
+//                 bodies of ICP/vtkPolyDataCorrespondenceFilter.cxx:110-136 /
+//                 274-305 and the solvers' O(n) loops.
+//
+// The winner is the exact minimum of (dist2, cell id) over all triangles:
+// a subtree is skipped only when the fp64 distance to its (outward-rounded)
+// box exceeds the best dist2 so far, so the traversal order cannot change it.
+#pragma once
+#include "../../include/icpx.h"
+#include "bvh.hpp"
+#include "tri.hpp"
+#include <stdint.h>
+
+namespace icpx
+{
+
+struct Xf
+{
+  double m[12]; // rows 0..2 of the 4x4
+};
+
+// vtkTransform::InternalTransformPoint on a float point promoted to double
+// (ICP/vtkPolyDataCorrespondenceFilter.cxx:116-119).
+__device__ __forceinline__ d3 xform(const Xf& T, const float* __restrict__ p)
+{
+  double x = (double)p[0], y = (double)p[1], z = (double)p[2];
+  return mk(T.m[0] * x + T.m[1] * y + T.m[2] * z + T.m[3],
+    T.m[4] * x + T.m[5] * y + T.m[6] * z + T.m[7],
+    T.m[8] * x + T.m[9] * y + T.m[10] * z + T.m[11]);
+}
+
+__device__ __forceinline__ void load_tri(
+  const float* __restrict__ tverts, int64_t s, d3& P0, d3& P1, d3& P2)
+{
+  const float* t = tverts + 9 * s;
+  P0 = mk((double)t[0], (double)t[1], (double)t[2]);
+  P1 = mk((double)t[3], (double)t[4], (double)t[5]);
+  P2 = mk((double)t[6], (double)t[7], (double)t[8]);
+}
+
+__device__ __forceinline__ bool better(double d2, int32_t id, double bd2, int32_t bid)
+{
+  return d2 < bd2 || (d2 == bd2 && id < bid);
+}
+
+struct SearchArgs
+{
+  const float* qpos; // query points in query-Morton order
+  int64_t nq;
+  Xf T;
+  const float* nodes;
+  TreeLevels lv;
+  const float* tverts;
+  const int32_t* tid;
+  int64_t nt;
+  int32_t* hint; // per query: sorted position of the winning triangle (in: last pass, out: this pass)
+  int use_hint;
+};
+
+template <int G>
+struct SearchCfg
+{
+  // deepest hierarchy the LDS stack is sized for (G^levels leaves)
+  static constexpr int LEVELS = (G == 4) ? 14 : (G == 8) ? 10 : (G == 16) ? 7 : (G == 32) ? 6 : 5;
+  static constexpr int STACK = (G - 1) * LEVELS + 2;
+  static constexpr int GPB = 256 / G; // queries per 256-thread block
+};
+
+template <int G>
+__global__ __launch_bounds__(256) void k_search(SearchArgs a)
+{
+  using Cfg = SearchCfg<G>;
+  __shared__ unsigned long long stack[Cfg::GPB][Cfg::STACK];
+  __shared__ int64_t s_off[MAXLEV + 1];
+  __shared__ int32_t s_cnt[MAXLEV + 1];
+  const int tid = threadIdx.x;
+  if (tid <= MAXLEV)
+  {
+    s_off[tid] = a.lv.off[tid];
+    s_cnt[tid] = a.lv.cnt[tid];
+  }
+  __syncthreads();
+  const int g = tid / G, j = tid % G;
+  const int lane = tid & 63;
+  const int gbase = lane & ~(G - 1);
+  const int64_t q = (int64_t)blockIdx.x * Cfg::GPB + g;
+  const bool active = q < a.nq;
+
+  d3 x = mk(0.0, 0.0, 0.0);
+  double best = INFINITY;
+  int32_t bestId = 0x7fffffff, bestS = -1;
+  int top = 0;
+  if (active)
+  {
+    x = xform(a.T, a.qpos + 3 * q);
+    if (a.use_hint)
+    {
+      int32_t hs = a.hint[q];
+      if (hs >= 0)
+      {
+        d3 P0, P1, P2, cp;
+        double d2, w[3];
+        load_tri(a.tverts, hs, P0, P1, P2);
+        if (tri_eval(x, P0, P1, P2, cp, d2, w))
+        {
+          best = d2;
+          bestS = hs;
+          bestId = a.tid[hs];
+        }
+      }
+    }
+    if (j == 0)
+      stack[g][0] = (unsigned long long)((uint32_t)a.lv.nlev << 28); // root, bound 0.0f
+    top = 1;
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  int32_t leaf = -1;
+  while (true)
+  {
+    // descend until this group holds a leaf to test or its stack is empty
+    while (leaf < 0 && top > 0)
+    {
+      unsigned long long e = stack[g][--top];
+      float lbf = __uint_as_float((uint32_t)(e >> 32));
+      if ((double)lbf > best)
+        continue;
+      uint32_t code = (uint32_t)e;
+      int L = (int)(code >> 28);
+      int32_t idx = (int32_t)(code & 0x0fffffffu);
+      if (L == 0)
+      {
+        leaf = idx;
+        break;
+      }
+      const int64_t child = (int64_t)idx * G + j;
+      const float* n = a.nodes + s_off[L] + (int64_t)idx * (6 * G) + j;
+      double lox = (double)n[0], loy = (double)n[G], loz = (double)n[2 * G];
+      double hix = (double)n[3 * G], hiy = (double)n[4 * G], hiz = (double)n[5 * G];
+      double dx = fmax(fmax(lox - x.x, x.x - hix), 0.0);
+      double dy = fmax(fmax(loy - x.y, x.y - hiy), 0.0);
+      double dz = fmax(fmax(loz - x.z, x.z - hiz), 0.0);
+      double lb = dx * dx + dy * dy + dz * dz;
+      const bool push = (child < s_cnt[L - 1]) && (lb <= best);
+      const double key = push ? lb : -INFINITY;
+      unsigned long long bal = __ballot(push);
+      uint32_t gm = (G == 64) ? 0u : (uint32_t)((bal >> gbase) & ((1ull << (G & 63)) - 1ull));
+      int npush = (G == 64) ? __popcll(bal) : __popc(gm);
+      // farther children go deeper in the stack; the nearest ends on top
+      int pos = 0;
+#pragma unroll
+      for (int i = 0; i < G; i++)
+      {
+        double o = __shfl(key, i, G);
+        pos += (o > key || (o == key && i > j)) ? 1 : 0;
+      }
+      if (push)
+      {
+        uint32_t c = ((uint32_t)(L - 1) << 28) | (uint32_t)child;
+        uint32_t f = __float_as_uint(__double2float_rd(lb));
+        stack[g][top + pos] = ((unsigned long long)f << 32) | c;
+      }
+      top += npush;
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (leaf < 0)
+      break;
+    // exact test of the leaf's triangles, one per lane
+    int64_t s = (int64_t)leaf * G + j;
+    double d2 = INFINITY;
+    int32_t id = 0x7fffffff;
+    int32_t sw = (int32_t)s;
+    if (s < a.nt)
+    {
+      d3 P0, P1, P2, cp;
+      double dd, w[3];
+      load_tri(a.tverts, s, P0, P1, P2);
+      if (tri_eval(x, P0, P1, P2, cp, dd, w))
+      {
+        d2 = dd;
+        id = a.tid[s];
+      }
+    }
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1)
+    {
+      double od = __shfl_xor(d2, m, G);
+      int32_t oi = __shfl_xor(id, m, G);
+      int32_t os = __shfl_xor(sw, m, G);
+      if (better(od, oi, d2, id))
+      {
+        d2 = od;
+        id = oi;
+        sw = os;
+      }
+    }
+    if (better(d2, id, best, bestId))
+    {
+      best = d2;
+      bestId = id;
+      bestS = sw;
+    }
+    leaf = -1;
+  }
+  if (active && j == 0)
+    a.hint[q] = bestS;
+}
+
+// ---------------------------------------------------------------- finalize ----
+struct FinalArgs
+{
+  const float* qpos;   // sorted query points
+  const float* qsn;    // sorted source normals (or null)
+  const int32_t* qk;   // sorted position -> kept index local to the shard
+  int64_t nq;
+  Xf T;
+  double origin[3];
+  const float* tverts;
+  const int32_t* tid;
+  const int32_t* tri;
+  const float* fnorm;
+  const float* enorm;
+  const float* vnorm;
+  const int32_t* hint;
+  double max_dist, min_dot;
+  int use_sn;
+  // rows, indexed by kept index (ROWS only)
+  float* o_origin;
+  float* o_onormal;
+  float* o_closest;
+  float* o_normal;
+  int32_t* o_cell;
+  double* o_dist;
+  uint32_t* o_flag;
+  // partial sums, [gridDim.x][ICPX_NSUMS] (sums only)
+  double* partials;
+};
+
+template <int METRIC>
+struct SumCfg
+{
+  static constexpr int N = (METRIC == 0) ? 17 : (METRIC == 1) ? 32 : 35;
+};
+
+// One accepted row into the metric's raw moments; s, t, n, sn are the float
+// rows promoted to double, o the moment origin.
+template <int METRIC>
+__device__ __forceinline__ void add_row(double* acc, const d3& s, const d3& t, const d3& n,
+  const d3& sn, const double* o)
+{
+  const d3 sp = mk(s.x - o[0], s.y - o[1], s.z - o[2]);
+  const d3 tp = mk(t.x - o[0], t.y - o[1], t.z - o[2]);
+  const d3 df = mk(s.x - t.x, s.y - t.y, s.z - t.z);
+  acc[0] += 1.0;
+  acc[1] += sqrt(df.x * df.x + df.y * df.y + df.z * df.z);
+  acc[2] += sp.x;
+  acc[3] += sp.y;
+  acc[4] += sp.z;
+  if (METRIC == 0)
+  {
+    acc[5] += tp.x;
+    acc[6] += tp.y;
+    acc[7] += tp.z;
+    acc[8] += sp.x * tp.x;
+    acc[9] += sp.x * tp.y;
+    acc[10] += sp.x * tp.z;
+    acc[11] += sp.y * tp.x;
+    acc[12] += sp.y * tp.y;
+    acc[13] += sp.y * tp.z;
+    acc[14] += sp.z * tp.x;
+    acc[15] += sp.z * tp.y;
+    acc[16] += sp.z * tp.z;
+  }
+  else
+  {
+    int b = 5;
+    d3 nn = n, u = sp;
+    if (METRIC == 2)
+    {
+      acc[5] += tp.x;
+      acc[6] += tp.y;
+      acc[7] += tp.z;
+      b = 8;
+      nn = mk(sn.x + n.x, sn.y + n.y, sn.z + n.z);
+      u = mk(sp.x + tp.x, sp.y + tp.y, sp.z + tp.z);
+    }
+    const d3 a = mk(u.y * nn.z - u.z * nn.y, u.z * nn.x - u.x * nn.z, u.x * nn.y - u.y * nn.x);
+    const double r = df.x * nn.x + df.y * nn.y + df.z * nn.z;
+    acc[b + 0] += a.x * a.x;
+    acc[b + 1] += a.x * a.y;
+    acc[b + 2] += a.x * a.z;
+    acc[b + 3] += a.y * a.y;
+    acc[b + 4] += a.y * a.z;
+    acc[b + 5] += a.z * a.z;
+    acc[b + 6] += a.x * nn.x;
+    acc[b + 7] += a.x * nn.y;
+    acc[b + 8] += a.x * nn.z;
+    acc[b + 9] += a.y * nn.x;
+    acc[b + 10] += a.y * nn.y;
+    acc[b + 11] += a.y * nn.z;
+    acc[b + 12] += a.z * nn.x;
+    acc[b + 13] += a.z * nn.y;
+    acc[b + 14] += a.z * nn.z;
+    acc[b + 15] += nn.x * nn.x;
+    acc[b + 16] += nn.x * nn.y;
+    acc[b + 17] += nn.x * nn.z;
+    acc[b + 18] += nn.y * nn.y;
+    acc[b + 19] += nn.y * nn.z;
+    acc[b + 20] += nn.z * nn.z;
+    acc[b + 21] += a.x * r;
+    acc[b + 22] += a.y * r;
+    acc[b + 23] += a.z * r;
+    acc[b + 24] += nn.x * r;
+    acc[b + 25] += nn.y * r;
+    acc[b + 26] += nn.z * r;
+  }
+}
+
+constexpr int FIN_THREADS = 256;
+
+template <int METRIC, bool ROWS>
+__global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalArgs a)
+{
+  constexpr int NS = SumCfg<METRIC>::N;
+  double acc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++)
+    acc[i] = 0.0;
+
+  const int64_t stride = (int64_t)gridDim.x * FIN_THREADS;
+  for (int64_t p = (int64_t)blockIdx.x * FIN_THREADS + threadIdx.x; p < a.nq; p += stride)
+  {
+    const d3 x = xform(a.T, a.qpos + 3 * p);
+    const int32_t hs = a.hint[p];
+    const int64_t k = a.qk[p];
+    bool accept = false;
+    float of[3] = { (float)x.x, (float)x.y, (float)x.z };
+    float cf[3] = { 0.f, 0.f, 0.f }, nf[3] = { 0.f, 0.f, 0.f }, sf[3] = { 0.f, 0.f, 0.f };
+    int32_t cell = -1;
+    double dist = 0.0;
+    if (hs >= 0)
+    {
+      d3 P0, P1, P2, pcl, cp;
+      double d2, w[3], d2b;
+      load_tri(a.tverts, hs, P0, P1, P2);
+      tri_eval(x, P0, P1, P2, pcl, d2, w);   // closest point p and vlen2 (:375)
+      dist = sqrt(d2);                        // :380
+      tri_eval(pcl, P0, P1, P2, cp, d2b, w);  // weights at p, closestPoint (:388)
+      cell = a.tid[hs];
+      const bool z0 = fabs(w[0]) < 1e-12, z1 = fabs(w[1]) < 1e-12, z2 = fabs(w[2]) < 1e-12;
+      const int count = (z0 ? 1 : 0) + (z1 ? 1 : 0) + (z2 ? 1 : 0);
+      const float* np = nullptr;
+      if (count == 0)
+        np = a.fnorm + 3 * (int64_t)cell;
+      else if (count == 1)
+      {
+        int e = z0 ? 0 : (z1 ? 1 : 2);
+        np = a.enorm + 3 * (3 * (int64_t)cell + e);
+      }
+      else if (count == 2)
+      {
+        int i = !z2 ? 2 : (!z1 ? 1 : 0); // the last weight above the tolerance (:460-466)
+        np = a.vnorm + 3 * (int64_t)a.tri[3 * (int64_t)cell + i];
+      }
+      if (np)
+      {
+        nf[0] = np[0];
+        nf[1] = np[1];
+        nf[2] = np[2];
+      }
+      cf[0] = (float)cp.x;
+      cf[1] = (float)cp.y;
+      cf[2] = (float)cp.z;
+      accept = dist < a.max_dist;
+      if (a.qsn)
+      {
+        sf[0] = a.qsn[3 * p];
+        sf[1] = a.qsn[3 * p + 1];
+        sf[2] = a.qsn[3 * p + 2];
+        if (a.use_sn)
+        {
+          double dn = (double)nf[0] * (double)sf[0] + (double)nf[1] * (double)sf[1] +
+            (double)nf[2] * (double)sf[2];
+          accept = accept && (dn > a.min_dot);
+        }
+      }
+    }
+    if (ROWS)
+    {
+      a.o_flag[k] = accept ? 1u : 0u;
+      if (accept)
+      {
+        for (int c = 0; c < 3; c++)
+        {
+          a.o_origin[3 * k + c] = of[c];
+          a.o_closest[3 * k + c] = cf[c];
+          a.o_normal[3 * k + c] = nf[c];
+          if (a.o_onormal)
+            a.o_onormal[3 * k + c] = sf[c];
+        }
+        a.o_cell[k] = cell;
+        a.o_dist[k] = dist;
+      }
+    }
+    else if (accept)
+    {
+      add_row<METRIC>(acc, mk((double)of[0], (double)of[1], (double)of[2]),
+        mk((double)cf[0], (double)cf[1], (double)cf[2]),
+        mk((double)nf[0], (double)nf[1], (double)nf[2]),
+        mk((double)sf[0], (double)sf[1], (double)sf[2]), a.origin);
+    }
+  }
+  if (ROWS)
+    return;
+
+  // fixed-shape reduction: lanes by xor-shuffle, waves through LDS, one partial per block
+  __shared__ double red[FIN_THREADS / 64][NS];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NS; i++)
+  {
+    double v = acc[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+      v += __shfl_xor(v, m, 64);
+    if (lane == 0)
+      red[wid][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < ICPX_NSUMS)
+  {
+    double v = 0.0;
+    if (threadIdx.x < NS)
+      for (int w = 0; w < FIN_THREADS / 64; w++)
+        v += red[w][threadIdx.x];
+    a.partials[(int64_t)blockIdx.x * ICPX_NSUMS + threadIdx.x] = v;
+  }
+}
+
+// Block partials -> the ICPX_NSUMS totals, summed in block order.
+__global__ __launch_bounds__(64) void k_reduce_partials(
+  const double* __restrict__ partials, int nblocks, double* __restrict__ sums)
+{
+  int t = threadIdx.x;
+  if (t >= ICPX_NSUMS)
+    return;
+  double v = 0.0;
+  for (int b = 0; b < nblocks; b++)
+    v += partials[(int64_t)b * ICPX_NSUMS + t];
+  sums[t] = v;
+}
+
+// Query set-up: gather the kept points (and normals) of the shard into Morton order.
+__global__ void k_gather_queries(const float* __restrict__ xyz, const float* __restrict__ nrm,
+  const uint32_t* __restrict__ order, int64_t k0, int64_t step, int64_t nq,
+  float* __restrict__ qpos, float* __restrict__ qsn, int32_t* __restrict__ qk,
+  int32_t* __restrict__ hint)
+{
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nq)
+    return;
+  uint32_t k = order[p];
+  int64_t i = (k0 + k) * step;
+  qpos[3 * p] = xyz[3 * i];
+  qpos[3 * p + 1] = xyz[3 * i + 1];
+  qpos[3 * p + 2] = xyz[3 * i + 2];
+  if (nrm)
+  {
+    qsn[3 * p] = nrm[3 * i];
+    qsn[3 * p + 1] = nrm[3 * i + 1];
+    qsn[3 * p + 2] = nrm[3 * i + 2];
+  }
+  qk[p] = (int32_t)k;
+  hint[p] = -1;
+}
+
+// K8: accepted rows, already in ascending kept-index order, packed to the front.
+struct CompactArgs
+{
+  int64_t nq, k0, step;
+  const uint32_t* flag;
+  const uint32_t* pos; // exclusive scan of flag
+  const float *origin, *onormal, *closest, *normal;
+  const int32_t* cell;
+  const double* dist;
+  float *d_origin, *d_onormal, *d_closest, *d_normal;
+  int32_t* d_cell;
+  double* d_dist;
+  int64_t* d_index;
+};
+
+__global__ void k_compact_rows(CompactArgs a)
+{
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.nq || !a.flag[k])
+    return;
+  int64_t r = a.pos[k];
+  for (int c = 0; c < 3; c++)
+  {
+    a.d_origin[3 * r + c] = a.origin[3 * k + c];
+    a.d_closest[3 * r + c] = a.closest[3 * k + c];
+    a.d_normal[3 * r + c] = a.normal[3 * k + c];
+    if (a.d_onormal)
+      a.d_onormal[3 * r + c] = a.onormal[3 * k + c];
+  }
+  a.d_cell[r] = a.cell[k];
+  a.d_dist[r] = a.dist[k];
+  a.d_index[r] = (a.k0 + k) * a.step;
+}
+
+} // namespace icpx

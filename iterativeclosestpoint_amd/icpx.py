@@ -1,0 +1,239 @@
+"""ctypes binding of libicpx (include/icpx.h).
+
+The library is the product; this module only marshals numpy arrays into the C
+ABI.  There is no CPU fallback: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+NSUMS = 40
+METRIC_POINT_TO_POINT = 0
+METRIC_POINT_TO_PLANE = 1
+METRIC_PLANE_TO_PLANE = 2
+
+E_INVALID, E_HIP, E_NOMEM, E_FEW = -1, -2, -3, -4
+RUN_MAX_ITERATIONS, RUN_CONVERGED, RUN_TOO_FEW = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libicpx.so")
+
+SYMBOLS = (
+    "icpx_last_error", "icpx_device_count", "icpx_create", "icpx_destroy", "icpx_set_stream",
+    "icpx_synchronize", "icpx_set_target", "icpx_set_source", "icpx_set_shard", "icpx_get_origin",
+    "icpx_accumulate", "icpx_correspond", "icpx_solve", "icpx_default_params",
+    "icpx_set_allreduce", "icpx_run", "icpx_last_build_seconds", "icpx_set_group_width",
+)
+
+
+class IcpxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("icpx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("metric", C.c_int), ("max_iterations", C.c_int), ("max_landmarks", C.c_int64),
+                ("max_distance", C.c_double), ("check_mean_distance", C.c_int),
+                ("max_mean_distance", C.c_double), ("min_normal_dot", C.c_double)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+
+_lib = None
+
+
+def load():
+    """Load libicpx.so from the package directory (built by __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libicpx.so is not built: run `make -C iterativeclosestpoint_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, dbl, ci = C.c_void_p, C.c_int64, C.c_double, C.c_int
+    lib.icpx_last_error.restype = C.c_char_p
+    lib.icpx_device_count.restype = ci
+    lib.icpx_create.argtypes = [C.POINTER(vp), ci]
+    lib.icpx_destroy.argtypes = [vp]
+    lib.icpx_destroy.restype = None
+    lib.icpx_set_stream.argtypes = [vp, vp]
+    lib.icpx_synchronize.argtypes = [vp]
+    lib.icpx_set_target.argtypes = [vp, vp, i64, vp, i64, vp]
+    lib.icpx_set_source.argtypes = [vp, vp, i64, vp]
+    lib.icpx_set_shard.argtypes = [vp, ci, ci]
+    lib.icpx_get_origin.argtypes = [vp, vp]
+    lib.icpx_accumulate.argtypes = [vp, ci, vp, i64, dbl, dbl, ci, vp, vp]
+    lib.icpx_correspond.argtypes = [vp, vp, i64, dbl, dbl, ci, vp, vp, vp, vp, vp, vp, vp,
+                                    C.POINTER(i64)]
+    lib.icpx_solve.argtypes = [ci, vp, vp, vp, C.POINTER(i64), C.POINTER(dbl)]
+    lib.icpx_default_params.argtypes = [C.POINTER(Params)]
+    lib.icpx_default_params.restype = None
+    lib.icpx_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    lib.icpx_run.argtypes = [vp, C.POINTER(Params), vp, C.POINTER(ci), C.POINTER(dbl),
+                             C.POINTER(ci)]
+    lib.icpx_last_build_seconds.argtypes = [vp]
+    lib.icpx_last_build_seconds.restype = dbl
+    lib.icpx_set_group_width.argtypes = [vp, ci]
+    _lib = lib
+    return lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise IcpxError(rc, load().icpx_last_error().decode())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return int(load().icpx_device_count())
+
+
+def default_params():
+    p = Params()
+    load().icpx_default_params(C.byref(p))
+    return p
+
+
+def solve(metric, sums, origin):
+    """Host solve of one iteration: returns (M 4x4, n, mean_distance, rc) with rc 0 or E_FEW."""
+    sums = np.ascontiguousarray(sums, np.float64)
+    origin = np.ascontiguousarray(origin, np.float64)
+    assert sums.size == NSUMS and origin.size == 3
+    M = np.zeros(16)
+    n = C.c_int64(0)
+    md = C.c_double(0)
+    rc = load().icpx_solve(int(metric), _p(sums), _p(origin), _p(M), C.byref(n), C.byref(md))
+    if rc not in (0, E_FEW):
+        _chk(rc)
+    return M.reshape(4, 4), n.value, md.value, rc
+
+
+class Context:
+    """One GPU's share of a registration (icpx_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        self._cb = None
+        _chk(load().icpx_create(C.byref(self._h), int(device)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            load().icpx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_ptr):
+        _chk(load().icpx_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        _chk(load().icpx_synchronize(self._h))
+
+    def set_group_width(self, lanes):
+        _chk(load().icpx_set_group_width(self._h, int(lanes)))
+
+    def set_target(self, xyz, tri, cell_normals=None):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        tri = np.ascontiguousarray(tri, np.int32).reshape(-1, 3)
+        cn = None
+        if cell_normals is not None:
+            cn = np.ascontiguousarray(cell_normals, np.float32).reshape(-1, 3)
+            if len(cn) != len(tri):
+                raise ValueError("cell_normals must have one row per triangle")
+        _chk(load().icpx_set_target(self._h, _p(xyz), len(xyz), _p(tri), len(tri), _p(cn)))
+
+    def set_source(self, xyz, normals=None):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        sn = None
+        if normals is not None:
+            sn = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+            if len(sn) != len(xyz):
+                raise ValueError("normals must have one row per point")
+        self._np = len(xyz)
+        _chk(load().icpx_set_source(self._h, _p(xyz), len(xyz), _p(sn)))
+
+    def set_shard(self, rank, world):
+        _chk(load().icpx_set_shard(self._h, int(rank), int(world)))
+
+    @property
+    def origin(self):
+        o = np.zeros(3)
+        _chk(load().icpx_get_origin(self._h, _p(o)))
+        return o
+
+    @property
+    def build_seconds(self):
+        return float(load().icpx_last_build_seconds(self._h))
+
+    def accumulate(self, metric, T, step=1, max_dist=10.0, min_dot=0.0, use_source_normals=None,
+                   device_ptr=None):
+        """Fused search + partial sums.  Returns the sums (numpy) unless device_ptr is given,
+        in which case they are left at that device address, stream-ordered."""
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        if use_source_normals is None:
+            use_source_normals = metric == METRIC_PLANE_TO_PLANE
+        if device_ptr:
+            _chk(load().icpx_accumulate(self._h, int(metric), _p(T), int(step), float(max_dist),
+                                        float(min_dot), int(bool(use_source_normals)), None,
+                                        C.c_void_p(device_ptr)))
+            return None
+        sums = np.zeros(NSUMS)
+        _chk(load().icpx_accumulate(self._h, int(metric), _p(T), int(step), float(max_dist),
+                                    float(min_dot), int(bool(use_source_normals)), _p(sums), None))
+        return sums
+
+    def correspond(self, T=None, step=1, max_dist=10.0, min_dot=0.0, use_source_normals=False):
+        """The correspondence filter's outputs: accepted rows in ascending source index."""
+        T = np.eye(4) if T is None else np.asarray(T, np.float64)
+        T = np.ascontiguousarray(T).reshape(16)
+        step = max(1, int(step))
+        nk = (self._np + step - 1) // step
+        out = dict(origin=np.zeros((nk, 3), np.float32),
+                   origin_normal=np.zeros((nk, 3), np.float32),
+                   closest=np.zeros((nk, 3), np.float32), normal=np.zeros((nk, 3), np.float32),
+                   cell=np.zeros(nk, np.int32), dist=np.zeros(nk, np.float64),
+                   src_index=np.zeros(nk, np.int64))
+        n = C.c_int64(0)
+        _chk(load().icpx_correspond(
+            self._h, _p(T), step, float(max_dist), float(min_dot), int(bool(use_source_normals)),
+            _p(out["origin"]), _p(out["origin_normal"]), _p(out["closest"]), _p(out["normal"]),
+            _p(out["cell"]), _p(out["dist"]), _p(out["src_index"]), C.byref(n)))
+        return {k: v[:n.value] for k, v in out.items()}
+
+    def set_allreduce(self, fn):
+        """fn(numpy view of the NSUMS sums) -> None; called once per iteration inside run()."""
+        if fn is None:
+            self._cb = ALLREDUCE_FN()
+        else:
+            def tramp(ptr, n, _user):
+                try:
+                    fn(np.ctypeslib.as_array(ptr, shape=(n,)))
+                    return 0
+                except Exception:  # surfaced as an icpx error by the library
+                    return 1
+            self._cb = ALLREDUCE_FN(tramp)
+        _chk(load().icpx_set_allreduce(self._h, self._cb, None))
+
+    def run(self, params):
+        """Whole vtkICP loop on this context. Returns (T 4x4, iterations, mean_distance, status)."""
+        T = np.zeros(16)
+        it, st, md = C.c_int(0), C.c_int(0), C.c_double(0)
+        _chk(load().icpx_run(self._h, C.byref(params), _p(T), C.byref(it), C.byref(md),
+                             C.byref(st)))
+        return T.reshape(4, 4), it.value, md.value, st.value
