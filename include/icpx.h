@@ -58,8 +58,9 @@ extern "C"
   int icpx_create(icpx_ctx** out, int device);
   void icpx_destroy(icpx_ctx* ctx);
 
-  /* Run the context's work on an existing HIP stream (hipStream_t passed as
-   * void*; NULL = the context's own stream). */
+  /* Run the context's work on the caller's HIP stream (hipStream_t passed as
+   * void*; NULL is HIP's null stream).  Until this is called the context uses a
+   * non-blocking stream of its own. */
   int icpx_set_stream(icpx_ctx* ctx, void* hip_stream);
 
   /* Wait for everything queued on the context's stream. */
@@ -171,6 +172,20 @@ extern "C"
    * one wavefront per query); 0 = choose from the number of queries. Changing
    * it rebuilds the tree on the next icpx_set_target. */
   int icpx_set_group_width(icpx_ctx* ctx, int lanes);
+
+  /* Forget the winners of the previous search pass.  A pass normally starts each
+   * query from the triangle that won last time (only as an upper bound: results
+   * do not depend on it); after this call the next pass starts cold, as the
+   * first iteration of a new vtkICP::Update() does. */
+  int icpx_reset_hints(icpx_ctx* ctx);
+
+  /* Measurement aid (no reference counterpart): record HIP events on the
+   * context's stream around every launch of the search kernel and of the
+   * finalize/reduction kernel.  icpx_get_timing synchronises and returns the
+   * accumulated kernel milliseconds and launch counts since timing was enabled. */
+  int icpx_set_timing(icpx_ctx* ctx, int enable);
+  int icpx_get_timing(icpx_ctx* ctx, double* search_ms, int64_t* search_launches,
+    double* finalize_ms, int64_t* finalize_launches);
 
 #ifdef __cplusplus
 }

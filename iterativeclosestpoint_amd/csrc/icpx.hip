@@ -16,6 +16,7 @@
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <new>
+#include <vector>
 
 using namespace icpx;
 
@@ -105,6 +106,81 @@ struct icpx_ctx
   int group_width = 0;
   icpx_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
+
+  // optional HIP-event timing of the two hot kernels
+  bool timing = false;
+  struct Pending
+  {
+    hipEvent_t a, b;
+    int which; // 0 search, 1 finalize
+  };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> free_events;
+  double t_ms[2] = { 0.0, 0.0 };
+  int64_t t_n[2] = { 0, 0 };
+};
+
+static hipEvent_t take_event(icpx_ctx* c)
+{
+  hipEvent_t e = nullptr;
+  if (!c->free_events.empty())
+  {
+    e = c->free_events.back();
+    c->free_events.pop_back();
+  }
+  else if (hipEventCreate(&e) != hipSuccess)
+    e = nullptr;
+  return e;
+}
+
+// Fold finished event pairs into the totals (the stream must be idle).
+static void resolve_timing(icpx_ctx* c)
+{
+  for (auto& p : c->pending)
+  {
+    float ms = 0.f;
+    if (p.a && p.b && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess)
+    {
+      c->t_ms[p.which] += ms;
+      c->t_n[p.which]++;
+    }
+    if (p.a)
+      c->free_events.push_back(p.a);
+    if (p.b)
+      c->free_events.push_back(p.b);
+  }
+  c->pending.clear();
+}
+
+struct ScopedTimer
+{
+  icpx_ctx* c;
+  hipEvent_t a = nullptr, b = nullptr;
+  int which;
+  ScopedTimer(icpx_ctx* ctx, int w)
+    : c(ctx)
+    , which(w)
+  {
+    if (!c->timing)
+      return;
+    if (c->pending.size() >= 4096)
+    {
+      (void)hipStreamSynchronize(c->stream);
+      resolve_timing(c);
+    }
+    a = take_event(c);
+    b = take_event(c);
+    if (a)
+      (void)hipEventRecord(a, c->stream);
+  }
+  ~ScopedTimer()
+  {
+    if (!c->timing)
+      return;
+    if (b)
+      (void)hipEventRecord(b, c->stream);
+    c->pending.push_back({ a, b, which });
+  }
 };
 
 template <typename T>
@@ -255,6 +331,9 @@ extern "C" void icpx_destroy(icpx_ctx* c)
   dev_free(&c->d_sums);
   if (c->h_sums)
     (void)hipHostFree(c->h_sums);
+  resolve_timing(c);
+  for (auto e : c->free_events)
+    (void)hipEventDestroy(e);
   if (c->own_stream)
     (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -266,7 +345,7 @@ extern "C" int icpx_set_stream(icpx_ctx* c, void* s)
     return fail(ICPX_E_INVALID, "null context");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
-  c->stream = s ? (hipStream_t)s : c->own_stream;
+  c->stream = (hipStream_t)s; // NULL is HIP's null stream
   return ICPX_OK;
 }
 
@@ -286,6 +365,46 @@ extern "C" int icpx_set_group_width(icpx_ctx* c, int lanes)
   if (lanes != 0 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64)
     return fail(ICPX_E_INVALID, "group width must be 0, 4, 8, 16, 32 or 64 (got %d)", lanes);
   c->group_width = lanes;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_timing(icpx_ctx* c, int enable)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  resolve_timing(c);
+  c->timing = enable != 0;
+  c->t_ms[0] = c->t_ms[1] = 0.0;
+  c->t_n[0] = c->t_n[1] = 0;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_get_timing(icpx_ctx* c, double* search_ms, int64_t* search_launches,
+  double* finalize_ms, int64_t* finalize_launches)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  resolve_timing(c);
+  if (search_ms)
+    *search_ms = c->t_ms[0];
+  if (search_launches)
+    *search_launches = c->t_n[0];
+  if (finalize_ms)
+    *finalize_ms = c->t_ms[1];
+  if (finalize_launches)
+    *finalize_launches = c->t_n[1];
+  return ICPX_OK;
+}
+
+extern "C" int icpx_reset_hints(icpx_ctx* c)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  c->hint_valid = false;
   return ICPX_OK;
 }
 
@@ -650,6 +769,7 @@ static int run_search(icpx_ctx* c, const double T[16])
   a.use_hint = c->hint_valid ? 1 : 0;
   const unsigned grid = nblk(c->nq, 256 / G);
   hipStream_t st = c->stream;
+  ScopedTimer tm(c, 0);
   switch (G)
   {
     case 4:
@@ -738,12 +858,15 @@ extern "C" int icpx_accumulate(icpx_ctx* c, int metric, const double T[16], int6
     int grid = (int)nblk(c->nq, FIN_THREADS);
     if (grid > c->max_blocks)
       grid = c->max_blocks;
-    if (metric == 0)
-      k_finalize<0, false><<<grid, FIN_THREADS, 0, st>>>(f);
-    else if (metric == 1)
-      k_finalize<1, false><<<grid, FIN_THREADS, 0, st>>>(f);
-    else
-      k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
+    {
+      ScopedTimer tm(c, 1);
+      if (metric == 0)
+        k_finalize<0, false><<<grid, FIN_THREADS, 0, st>>>(f);
+      else if (metric == 1)
+        k_finalize<1, false><<<grid, FIN_THREADS, 0, st>>>(f);
+      else
+        k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
+    }
     k_reduce_partials<<<1, 64, 0, st>>>(c->d_partials, grid, dst);
     LAUNCHCHK();
   }
@@ -875,6 +998,7 @@ extern "C" int icpx_run(icpx_ctx* c, const icpx_params* p, double T_out[16], int
   double T[16];
   for (int i = 0; i < 16; i++)
     T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  c->hint_valid = false; // every Update() starts cold
   int64_t step = 1;
   if (c->np > p->max_landmarks)
     step = c->np / p->max_landmarks; // vtkPolyDataCorrespondenceFilter.cxx:473-477

@@ -24,6 +24,7 @@ SYMBOLS = (
     "icpx_synchronize", "icpx_set_target", "icpx_set_source", "icpx_set_shard", "icpx_get_origin",
     "icpx_accumulate", "icpx_correspond", "icpx_solve", "icpx_default_params",
     "icpx_set_allreduce", "icpx_run", "icpx_last_build_seconds", "icpx_set_group_width",
+    "icpx_reset_hints", "icpx_set_timing", "icpx_get_timing",
 )
 
 
@@ -77,6 +78,10 @@ def load():
     lib.icpx_last_build_seconds.argtypes = [vp]
     lib.icpx_last_build_seconds.restype = dbl
     lib.icpx_set_group_width.argtypes = [vp, ci]
+    lib.icpx_reset_hints.argtypes = [vp]
+    lib.icpx_set_timing.argtypes = [vp, ci]
+    lib.icpx_get_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl),
+                                    C.POINTER(i64)]
     _lib = lib
     return lib
 
@@ -144,6 +149,19 @@ class Context:
 
     def synchronize(self):
         _chk(load().icpx_synchronize(self._h))
+
+    def reset_hints(self):
+        _chk(load().icpx_reset_hints(self._h))
+
+    def set_timing(self, enable=True):
+        _chk(load().icpx_set_timing(self._h, int(bool(enable))))
+
+    def get_timing(self):
+        """(search_ms, search_launches, finalize_ms, finalize_launches) since set_timing."""
+        a, b = C.c_double(0), C.c_double(0)
+        na, nb = C.c_int64(0), C.c_int64(0)
+        _chk(load().icpx_get_timing(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
+        return a.value, na.value, b.value, nb.value
 
     def set_group_width(self, lanes):
         _chk(load().icpx_set_group_width(self._h, int(lanes)))

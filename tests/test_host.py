@@ -1,0 +1,193 @@
+"""CPU tests of the host side of the product: the C ABI library loads and exports every
+symbol include/icpx.h declares, icpx_solve agrees with the oracle's solvers, the iterate
+loop and the sharded (world_size 2, gloo) driver reproduce the oracle's registration when
+fed per-shard sums.  No GPU work is launched here."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import rel_err, sums_from_rows
+from iterativeclosestpoint_amd import icpx, synth
+from iterativeclosestpoint_amd.distributed import shard_bounds
+from iterativeclosestpoint_amd.vtkicp import icp_loop, vtkICP, vtkPolyData
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "icpx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(icpx_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"icpx_allreduce_fn"}
+    assert len(declared) >= 20
+    lib = icpx.load()
+    for name in declared:
+        assert hasattr(lib, name), "libicpx.so does not export %s" % name
+    assert declared == set(icpx.SYMBOLS)
+
+
+def test_no_gpu_means_loud_failure():
+    if icpx.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(icpx.IcpxError):
+        icpx.Context(0)
+    icp = vtkICP()
+    xyz, tri = synth.bumpy_torus(8, 4)
+    icp.SetSource(vtkPolyData(xyz, tri))
+    icp.SetTarget(vtkPolyData(xyz, tri))
+    with pytest.raises(icpx.IcpxError):
+        icp.Update()          # no silent CPU fallback
+
+
+@pytest.mark.parametrize("metric", (0, 1, 2))
+def test_solve_matches_oracle(oracle, metric):
+    c = synth.config_c1()
+    mesh = oracle.Mesh(c["target_xyz"], c["target_tri"])
+    sn = synth.vertex_normals(c["source_xyz"], c["target_tri"])
+    rows = mesh.correspond(c["source_xyz"], step=3, src_normals=sn)
+    for o in (np.zeros(3), np.array([0.1, -0.2, 0.05]), np.array([50.0, -20.0, 7.0])):
+        sums = sums_from_rows(metric, rows["origin"], rows["closest"], rows["normal"],
+                              rows["origin_normal"], o)
+        M, n, md, rc = icpx.solve(metric, sums, o)
+        Mo, st = oracle.solve(metric, rows["origin"], rows["closest"], rows["origin_normal"],
+                              rows["normal"])
+        assert rc == 0 and st == 0 and n == len(rows["cell"])
+        assert rel_err(M, Mo) < (1e-12 if np.abs(o).max() < 1 else 1e-8)
+    d = rows["origin"].astype(np.float64) - rows["closest"].astype(np.float64)
+    assert np.isclose(md, np.sqrt((d ** 2).sum(1)).mean(), rtol=1e-12)
+
+
+def test_solve_rank_deficient_and_few():
+    z = np.zeros(icpx.NSUMS)
+    M, n, md, rc = icpx.solve(1, z, np.zeros(3))
+    assert rc == icpx.E_FEW and np.array_equal(M, np.eye(4))
+    # a flat patch: point-to-plane is singular in 3 of 6 unknowns; LDL^T zeroes them
+    g = np.stack(np.meshgrid(np.linspace(-1, 1, 9), np.linspace(-1, 1, 9)), -1).reshape(-1, 2)
+    t = np.concatenate([g, np.zeros((len(g), 1))], 1).astype(np.float32)
+    s = t + np.float32([0, 0, 0.25])
+    nrm = np.tile(np.float32([0, 0, 1]), (len(g), 1))
+    sums = sums_from_rows(1, s, t, nrm, None, np.zeros(3))
+    M, n, md, rc = icpx.solve(1, sums, np.zeros(3))
+    assert rc == 0 and np.all(np.isfinite(M))
+    assert np.allclose(M, [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, -0.25], [0, 0, 0, 1]], atol=1e-12)
+
+
+def oracle_accumulate(mesh, src, sn, metric, step, max_dist, origin, k0=0, k1=None):
+    """Per-shard sums as the GPU would produce them, from oracle rows."""
+    def acc(T):
+        rows = mesh.correspond(src, T=T, step=step, max_dist=max_dist,
+                               src_normals=sn if metric == 2 else None)
+        k = rows["src_index"] // step
+        sel = (k >= k0) & (k < (k1 if k1 is not None else 1 << 62))
+        return sums_from_rows(metric, rows["origin"][sel], rows["closest"][sel],
+                              rows["normal"][sel], rows["origin_normal"][sel], origin)
+    return acc
+
+
+@pytest.mark.parametrize("metric", (0, 1, 2))
+def test_icp_loop_matches_oracle(oracle, metric):
+    c = synth.config_c1()
+    mesh = oracle.Mesh(c["target_xyz"], c["target_tri"])
+    sn = synth.vertex_normals(c["source_xyz"], c["target_tri"])
+    origin = 0.5 * (c["target_xyz"].min(0) + c["target_xyz"].max(0)).astype(np.float64)
+    step = len(c["source_xyz"]) // 100
+    T, it, md, st = icp_loop(oracle_accumulate(mesh, c["source_xyz"], sn, metric, step, 10.0,
+                                               origin), None, origin, metric, 20, True, 1e-7)
+    To, ito, mo, sto, n = mesh.icp(c["source_xyz"], metric=metric, max_iter=20,
+                                   max_landmarks=100, check_mean=True, max_mean=1e-7,
+                                   src_normals=sn)
+    assert (it, st) == (ito, sto) and rel_err(T, To) < 1e-9 and abs(md - mo) < 1e-12
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, metric, q):
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    from iterativeclosestpoint_amd.distributed import make_allreduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = synth.config_c1()
+    mesh = orc.Mesh(c["target_xyz"], c["target_tri"])
+    sn = synth.vertex_normals(c["source_xyz"], c["target_tri"])
+    origin = 0.5 * (c["target_xyz"].min(0) + c["target_xyz"].max(0)).astype(np.float64)
+    step = len(c["source_xyz"]) // 200
+    nk = -(-len(c["source_xyz"]) // step)
+    k0, k1 = shard_bounds(nk, rank, world)
+    acc = oracle_accumulate(mesh, c["source_xyz"], sn, metric, step, 10.0, origin, k0, k1)
+    T, it, md, st = icp_loop(acc, make_allreduce(), origin, metric, 8, False, 0.0)
+    q.put((rank, T, it, st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric", (1, 2))
+def test_sharded_loop_world2_gloo(oracle, metric):
+    """Two ranks, each summing its block of the kept indices, one all-reduce per iteration:
+    both end with the transform of the unsharded registration."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, metric, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    c = synth.config_c1()
+    mesh = oracle.Mesh(c["target_xyz"], c["target_tri"])
+    sn = synth.vertex_normals(c["source_xyz"], c["target_tri"])
+    To, ito, mo, sto, n = mesh.icp(c["source_xyz"], metric=metric, max_iter=8, max_landmarks=200,
+                                   src_normals=sn)
+    assert np.array_equal(res[0][1], res[1][1])          # no broadcast needed: identical solves
+    assert res[0][2] == ito and rel_err(res[0][1], To) < 1e-9
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 100, 103, 16_000_000):
+        for w in (1, 2, 3, 4, 8):
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(k1 - k0 for k0, k1 in b) - min(k1 - k0 for k0, k1 in b) <= 1
+
+
+def test_vtkicp_defaults_and_errors(capsys):
+    icp = vtkICP.New()
+    assert icp.GetMaximumNumberOfIterations() == 50          # vtkICP.cxx:31
+    assert icp.GetCheckMeanDistance() is False and icp.GetMaximumMeanDistance() == 0.01
+    assert icp.GetMaximumDistance() == 10.0 and icp.GetMetric() == vtkICP.MetricPointToPlane
+    assert icp.GetMaximumNumberOfLandmarks() == 200          # vtkICP.h:52-59
+    icp.SetMetric(7)
+    assert icp.GetMetric() == 2 and icp.GetMetricModeAsString() == "Plane-to-plane"
+    icp.SetMetric(-3)
+    assert icp.GetMetricModeAsString() == "Point-to-point"
+    icp.Update()                                             # no source: error, identity kept
+    assert "empty input" in capsys.readouterr().err
+    assert np.array_equal(icp.Matrix, np.eye(4))
+    xyz, tri = synth.bumpy_torus(8, 4)
+    icp.SetSource(vtkPolyData(xyz, tri))
+    icp.Update()
+    assert "empty target" in capsys.readouterr().err
+    icp.SetTarget(vtkPolyData(xyz.astype(np.float64), tri))
+    icp.Update()
+    assert "single-precision" in capsys.readouterr().err
+    icp.SetTarget(vtkPolyData(xyz, tri))
+    icp.SetMetricToPlaneToPlane()
+    icp.Update()
+    assert "requires source normals" in capsys.readouterr().err
+    other = icp.MakeTransform()
+    other.DeepCopy(icp)
+    assert other.GetMetric() == icp.GetMetric() and other.GetSource() is icp.GetSource()
