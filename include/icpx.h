@@ -168,10 +168,23 @@ extern "C"
    * tables on the device (for reporting; not part of the reference surface). */
   double icpx_last_build_seconds(icpx_ctx* ctx);
 
-  /* Search-kernel variant: lanes that cooperate on one query (4, 8, 16, 32 or 64 =
-   * one wavefront per query); 0 = choose from the number of queries. Changing
-   * it rebuilds the tree on the next icpx_set_target. */
+  /* Search-kernel variant: lanes that cooperate on one query.  1 = one lane per
+   * query over a binary box tree (large clouds); 4, 8, 16, 32 or 64 = that many
+   * lanes per query over a tree of the same fan-out (64 = one wavefront per
+   * query, for a few hundred landmarks); 0 = choose from the number of queries.
+   * Trees are built on first use.  Results do not depend on the choice. */
   int icpx_set_group_width(icpx_ctx* ctx, int lanes);
+
+  /* Triangles per leaf of the lane-per-query kernel's tree: 1, 2 (default) or 4. */
+  int icpx_set_leaf_size(icpx_ctx* ctx, int triangles);
+
+  /* Search kernel selection.  0 (default): the production kernel, which screens
+   * triangles with a short fp64 routine and evaluates only near-ties (within
+   * 1e-9 x the largest coordinate of the minimum) with the reference's exact
+   * arithmetic.  1: the exhaustive kernel, which evaluates every visited
+   * triangle exactly.  Both return the same winners; the second exists as a
+   * cross-check. */
+  int icpx_set_exhaustive(icpx_ctx* ctx, int enable);
 
   /* Forget the winners of the previous search pass.  A pass normally starts each
    * query from the triangle that won last time (only as an upper bound: results

@@ -7,6 +7,8 @@
 #include "bvh.hpp"
 #include "prims.hpp"
 #include "query.hpp"
+#include "search2.hpp"
+#include "search3.hpp"
 #include "tables.hpp"
 
 #include <chrono>
@@ -15,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -50,6 +53,18 @@ struct Tree
   float* nodes = nullptr;
   bool built = false;
 };
+struct Heap
+{
+  HeapTree t;
+  float* nodes = nullptr;
+  bool built = false;
+};
+struct Bin
+{
+  BinTree t;
+  float* nodes = nullptr;
+  bool built = false;
+};
 
 struct icpx_ctx
 {
@@ -65,7 +80,19 @@ struct icpx_ctx
   float *d_fn = nullptr, *d_en = nullptr, *d_vn = nullptr;
   Box3 box;
   double origin[3] = { 0, 0, 0 };
-  Tree trees[5];
+  Tree trees[5];  // exhaustive-exact kernel's level-array trees
+  Heap heaps[5];  // group kernel's heap-ordered trees
+  Bin bins[3];    // lane-per-query kernel's binary trees (1, 2, 4 triangles per leaf)
+  int leaf_size = 2;
+  // lane-per-query kernel's tie bookkeeping, sized for q3_cap queries
+  int64_t q3_cap = 0;
+  int32_t* d_cand = nullptr;
+  uint2* d_tie_list = nullptr;
+  uint32_t* d_counters = nullptr;
+  uint32_t* d_ovf_list = nullptr;
+  double* d_ovf_best = nullptr;
+  float scene_max = 0.f;
+  int exhaustive = 0;
   double build_seconds = 0.0;
 
   // source
@@ -236,6 +263,16 @@ static void free_target(icpx_ctx* c)
     dev_free(&t.nodes);
     t.built = false;
   }
+  for (auto& t : c->heaps)
+  {
+    dev_free(&t.nodes);
+    t.built = false;
+  }
+  for (auto& t : c->bins)
+  {
+    dev_free(&t.nodes);
+    t.built = false;
+  }
   c->nv = c->nt = 0;
 }
 static void free_queries(icpx_ctx* c)
@@ -244,7 +281,13 @@ static void free_queries(icpx_ctx* c)
   dev_free(&c->d_qsn);
   dev_free(&c->d_qk);
   dev_free(&c->d_hint);
+  dev_free(&c->d_cand);
+  dev_free(&c->d_tie_list);
+  dev_free(&c->d_counters);
+  dev_free(&c->d_ovf_list);
+  dev_free(&c->d_ovf_best);
   c->q_cap = 0;
+  c->q3_cap = 0;
   c->prep_step = -1;
 }
 static void free_rows(icpx_ctx* c)
@@ -362,8 +405,9 @@ extern "C" int icpx_set_group_width(icpx_ctx* c, int lanes)
 {
   if (!c)
     return fail(ICPX_E_INVALID, "null context");
-  if (lanes != 0 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64)
-    return fail(ICPX_E_INVALID, "group width must be 0, 4, 8, 16, 32 or 64 (got %d)", lanes);
+  if (lanes != 0 && lanes != 1 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 &&
+    lanes != 64)
+    return fail(ICPX_E_INVALID, "group width must be 0, 1, 4, 8, 16, 32 or 64 (got %d)", lanes);
   c->group_width = lanes;
   return ICPX_OK;
 }
@@ -397,6 +441,61 @@ extern "C" int icpx_get_timing(icpx_ctx* c, double* search_ms, int64_t* search_l
     *finalize_ms = c->t_ms[1];
   if (finalize_launches)
     *finalize_launches = c->t_n[1];
+  return ICPX_OK;
+}
+
+// Diagnostic: copy internal arrays to the host. what: 0 = winners of the last search pass
+// (Morton positions, int32 x nq), 1 = Morton position -> cell id (int32 x nt, -1-id for
+// degenerate), 2 = {ties, overflows} of the last lane-per-query pass (uint32 x 2).
+extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
+{
+  if (!c || !out)
+    return fail(ICPX_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const void* src = nullptr;
+  size_t bytes = 0;
+  if (what == 0)
+  {
+    src = c->d_hint;
+    bytes = sizeof(int32_t) * (size_t)std::min<int64_t>(count, c->nq);
+  }
+  else if (what == 1)
+  {
+    src = c->d_tid;
+    bytes = sizeof(int32_t) * (size_t)std::min<int64_t>(count, c->nt);
+  }
+  else if (what == 2 && c->d_counters)
+  {
+    src = c->d_counters;
+    bytes = sizeof(uint32_t) * 2;
+  }
+  else if (what == 3 && c->d_ovf_best)
+  {
+    src = c->d_ovf_best;
+    bytes = sizeof(double) * (size_t)std::min<int64_t>(count, c->nq);
+  }
+  if (!src)
+    return fail(ICPX_E_INVALID, "nothing to dump");
+  HIPCHK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_leaf_size(icpx_ctx* c, int triangles)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  if (triangles != 1 && triangles != 2 && triangles != 4)
+    return fail(ICPX_E_INVALID, "leaf size must be 1, 2 or 4 (got %d)", triangles);
+  c->leaf_size = triangles;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_exhaustive(icpx_ctx* c, int enable)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  c->exhaustive = enable ? 1 : 0;
   return ICPX_OK;
 }
 
@@ -486,6 +585,9 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
     c->box.inv[a] = ext > 0.f ? 1.f / ext : 0.f;
     c->origin[a] = 0.5 * ((double)lo[a] + (double)hi[a]);
   }
+  c->scene_max = 0.f;
+  for (int a = 0; a < 3; a++)
+    c->scene_max = std::fmax(c->scene_max, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
 
   ALLOC(c->d_xyz, 3 * nv);
   ALLOC(c->d_tri, 3 * nt);
@@ -524,6 +626,7 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   int which = radix_sort_pairs(k0, v0, k1, v1, nt, 63, scr, st);
   k_gather_tris<<<nblk(nt, 256), 256, 0, st>>>(
     c->d_xyz, c->d_tri, which ? v1 : v0, nt, c->d_tverts, c->d_tid);
+  k_flag_degenerate<<<nblk(nt, 256), 256, 0, st>>>(c->d_tverts, nt, c->d_tid);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess)
     e = hipStreamSynchronize(st);
@@ -620,6 +723,36 @@ static int ensure_tree(icpx_ctx* c, int G)
     k_build_level<<<nblk((int64_t)t.lv.cnt[L] * G, 256), 256, 0, st>>>(L, t.lv, t.nodes);
   LAUNCHCHK();
   t.built = true;
+  return ICPX_OK;
+}
+
+static int ensure_heap(icpx_ctx* c, int G)
+{
+  int slot = -1;
+  for (int i = 0; i < 5; i++)
+    if (kWidths[i] == G)
+      slot = i;
+  if (slot < 0)
+    return fail(ICPX_E_INVALID, "bad group width %d", G);
+  Heap& h = c->heaps[slot];
+  if (h.built)
+    return ICPX_OK;
+  h.t = make_heap_tree(c->nt, G);
+  int maxlev = (G == 4) ? Search2Cfg<4>::LEVELS
+                        : (G == 8) ? Search2Cfg<8>::LEVELS
+                                   : (G == 16) ? Search2Cfg<16>::LEVELS
+                                               : (G == 32) ? Search2Cfg<32>::LEVELS
+                                                           : Search2Cfg<64>::LEVELS;
+  if (h.t.depth > maxlev || h.t.first_leaf + h.t.leaf_cap >= (1ll << 32))
+    return fail(ICPX_E_INVALID, "target too large for fan-out %d", G);
+  ALLOC(h.nodes, h.t.first_leaf * 6 * G);
+  hipStream_t st = c->stream;
+  k_heap_bottom<<<nblk(h.t.leaf_cap, 256), 256, 0, st>>>(
+    c->d_tverts, c->d_tid, c->nt, h.t, h.nodes);
+  for (int k = h.t.depth - 2; k >= 0; k--)
+    k_heap_level<<<nblk(ipow(G, k + 1), 256), 256, 0, st>>>(k, h.t, h.nodes);
+  LAUNCHCHK();
+  h.built = true;
   return ICPX_OK;
 }
 
@@ -727,34 +860,165 @@ static int prepare_queries(icpx_ctx* c, int64_t step)
   return ICPX_OK;
 }
 
-static int pick_width(const icpx_ctx* c)
-{
-  if (c->group_width)
-    return c->group_width;
-  // few queries: spend a whole wavefront on each; many: 8 queries per wavefront
-  if (c->nq <= 16384)
-    return 64;
-  if (c->nq <= 131072)
-    return 16;
-  return 8;
-}
-
 static void fill_xf(Xf& x, const double T[16])
 {
   for (int i = 0; i < 12; i++)
     x.m[i] = T[i];
 }
 
+static int pick_width(const icpx_ctx* c)
+{
+  if (c->group_width)
+    return (c->exhaustive && c->group_width == 1) ? 8 : c->group_width;
+  // few queries: spend a whole wavefront on each; many: one lane each
+  if (c->nq <= 4096)
+    return 64;
+  if (c->nq <= 32768 || c->exhaustive)
+    return 8;
+  return 1;
+}
+
+static int ensure_bin(icpx_ctx* c, int L)
+{
+  const int slot = (L == 1) ? 0 : (L == 2) ? 1 : 2;
+  Bin& b = c->bins[slot];
+  if (b.built)
+    return ICPX_OK;
+  b.t = make_bin_tree(c->nt, L);
+  if (b.t.depth > 30)
+    return fail(ICPX_E_INVALID, "target too large");
+  ALLOC(b.nodes, (1ll << b.t.depth) * NODE_FLOATS);
+  hipStream_t st = c->stream;
+  k_bin_bottom<<<nblk(1ll << b.t.depth, 256), 256, 0, st>>>(
+    c->d_tverts, c->d_tid, c->nt, b.t, b.nodes);
+  for (int k = b.t.depth - 2; k >= 0; k--)
+    k_bin_level<<<nblk(2ll << k, 256), 256, 0, st>>>(k, b.nodes);
+  LAUNCHCHK();
+  b.built = true;
+  return ICPX_OK;
+}
+
+template <int L>
+static void launch_search3(const Search3Args& a, unsigned grid, hipStream_t st)
+{
+  k_search3<L, false><<<grid, 256, 0, st>>>(a);
+  unsigned rgrid = grid / 8 + 1;
+  if (rgrid > 2048)
+    rgrid = 2048;
+  k_resolve_ties<<<rgrid, 256, 0, st>>>(a);
+  k_search3<L, true><<<grid, 256, 0, st>>>(a);
+}
+
+static int run_search3(icpx_ctx* c, const double T[16])
+{
+  const int L = c->leaf_size;
+  int rc = ensure_bin(c, L);
+  if (rc)
+    return rc;
+  if (c->nq > c->q3_cap)
+  {
+    ALLOC(c->d_cand, c->nq * RING3);
+    ALLOC(c->d_tie_list, c->nq);
+    ALLOC(c->d_counters, 2);
+    ALLOC(c->d_ovf_list, c->nq);
+    ALLOC(c->d_ovf_best, c->nq);
+    c->q3_cap = c->nq;
+  }
+  const Bin& b = c->bins[(L == 1) ? 0 : (L == 2) ? 1 : 2];
+  Search3Args a;
+  a.qpos = c->d_qpos;
+  a.nq = c->nq;
+  fill_xf(a.T, T);
+  a.nodes = b.nodes;
+  a.tree = b.t;
+  a.tverts = c->d_tverts;
+  a.tid = c->d_tid;
+  a.nt = c->nt;
+  a.hint = c->d_hint;
+  a.use_hint = c->hint_valid ? 1 : 0;
+  a.scene_max = c->scene_max;
+  a.cand = c->d_cand;
+  a.tie_list = c->d_tie_list;
+  a.counters = c->d_counters;
+  a.ovf_list = c->d_ovf_list;
+  a.ovf_best = c->d_ovf_best;
+  hipStream_t st = c->stream;
+  const unsigned grid = nblk(c->nq, 256);
+  ScopedTimer tm(c, 0);
+  HIPCHK(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(uint32_t), st));
+  if (L == 1)
+    launch_search3<1>(a, grid, st);
+  else if (L == 2)
+    launch_search3<2>(a, grid, st);
+  else
+    launch_search3<4>(a, grid, st);
+  LAUNCHCHK();
+  c->hint_valid = true;
+  return ICPX_OK;
+}
+
+
+template <int G>
+static void launch_search2(const Search2Args& a, unsigned grid, hipStream_t st)
+{
+  k_search2<G><<<grid, 256, 0, st>>>(a);
+}
+
 static int run_search(icpx_ctx* c, const double T[16])
 {
   const int G = pick_width(c);
-  int rc = ensure_tree(c, G);
-  if (rc)
-    return rc;
+  if (G == 1)
+    return run_search3(c, T);
   int slot = 0;
   for (int i = 0; i < 5; i++)
     if (kWidths[i] == G)
       slot = i;
+  const unsigned grid = nblk(c->nq, 256 / G);
+  hipStream_t st = c->stream;
+  if (!c->exhaustive)
+  {
+    int rc = ensure_heap(c, G);
+    if (rc)
+      return rc;
+    const Heap& h = c->heaps[slot];
+    Search2Args a;
+    a.qpos = c->d_qpos;
+    a.nq = c->nq;
+    fill_xf(a.T, T);
+    a.nodes = h.nodes;
+    a.tree = h.t;
+    a.tverts = c->d_tverts;
+    a.tid = c->d_tid;
+    a.nt = c->nt;
+    a.hint = c->d_hint;
+    a.use_hint = c->hint_valid ? 1 : 0;
+    a.scene_max = c->scene_max;
+    ScopedTimer tm(c, 0);
+    switch (G)
+    {
+      case 4:
+        launch_search2<4>(a, grid, st);
+        break;
+      case 8:
+        launch_search2<8>(a, grid, st);
+        break;
+      case 16:
+        launch_search2<16>(a, grid, st);
+        break;
+      case 32:
+        launch_search2<32>(a, grid, st);
+        break;
+      default:
+        launch_search2<64>(a, grid, st);
+        break;
+    }
+    LAUNCHCHK();
+    c->hint_valid = true;
+    return ICPX_OK;
+  }
+  int rc = ensure_tree(c, G);
+  if (rc)
+    return rc;
   const Tree& t = c->trees[slot];
   SearchArgs a;
   a.qpos = c->d_qpos;
@@ -767,8 +1031,6 @@ static int run_search(icpx_ctx* c, const double T[16])
   a.nt = c->nt;
   a.hint = c->d_hint;
   a.use_hint = c->hint_valid ? 1 : 0;
-  const unsigned grid = nblk(c->nq, 256 / G);
-  hipStream_t st = c->stream;
   ScopedTimer tm(c, 0);
   switch (G)
   {
@@ -867,7 +1129,7 @@ extern "C" int icpx_accumulate(icpx_ctx* c, int metric, const double T[16], int6
       else
         k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
     }
-    k_reduce_partials<<<1, 64, 0, st>>>(c->d_partials, grid, dst);
+    k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst);
     LAUNCHCHK();
   }
   if (sums_host)

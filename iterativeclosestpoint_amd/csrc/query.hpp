@@ -450,17 +450,21 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalArgs a)
   }
 }
 
-// Block partials -> the ICPX_NSUMS totals, summed in block order.
+// Block partials -> the ICPX_NSUMS totals.  One 64-lane block per sum: lane l adds
+// partials l, l+64, ... in that order, then a fixed xor-shuffle tree; the shape
+// depends only on the number of blocks, so results repeat run to run.
 __global__ __launch_bounds__(64) void k_reduce_partials(
   const double* __restrict__ partials, int nblocks, double* __restrict__ sums)
 {
-  int t = threadIdx.x;
-  if (t >= ICPX_NSUMS)
-    return;
+  const int i = blockIdx.x, l = threadIdx.x;
   double v = 0.0;
-  for (int b = 0; b < nblocks; b++)
-    v += partials[(int64_t)b * ICPX_NSUMS + t];
-  sums[t] = v;
+  for (int b = l; b < nblocks; b += 64)
+    v += partials[(int64_t)b * ICPX_NSUMS + i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+    v += __shfl_xor(v, m, 64);
+  if (l == 0)
+    sums[i] = v;
 }
 
 // Query set-up: gather the kept points (and normals) of the shard into Morton order.

@@ -1,0 +1,367 @@
+// search3.hpp — closest-triangle search for large clouds: one lane per query.
+//
+// With millions of queries the scarce resource is wave-instructions per query,
+// so here every lane walks its own query through a complete *binary* box
+// hierarchy (heap order: children of n are 2n, 2n+1; a node record holds both
+// children's boxes in one 64-byte line).  There is no stack: a 32-bit trail
+// keeps one bit per level ("the other child of this ancestor is still owed a
+// visit"), and coming back up re-tests that child's box from its parent's
+// record against the bound as it stands by then.  Queries are in Morton order,
+// so neighbouring lanes read the same lines and leave the loop together.
+//
+// Screening and exactness are as in search2.hpp: fp32 box distances that can
+// only under-estimate, a short fp64 routine to screen triangles, and the exact
+// routine of tri.hpp only for near-ties (within 1e-9 x the largest coordinate
+// of the minimum).  A query whose minimum is not contested is finished by this
+// kernel; contested ones (2..8 contenders) are listed and settled by
+// k_resolve_ties, eight lanes per query, one contender per lane; the rare query
+// with more contenders than the ring holds is re-run by k_search3 in its
+// EXACT mode, which knows the final bound and evaluates every contender
+// exactly as it meets it.
+//
+// Replaces vtkCellLocator::FindClosestPoint as called from
+// ICP/vtkImplicitPolyDataDistance2.cxx:375.
+#pragma once
+#include "search2.hpp"
+
+namespace icpx
+{
+
+struct BinTree
+{
+  int depth;     // leaves are heap numbers [2^depth, 2^(depth+1))
+  int L;         // triangles per leaf
+  int64_t nleaf; // leaves in use
+};
+
+inline BinTree make_bin_tree(int64_t nt, int L)
+{
+  BinTree t;
+  t.L = L;
+  t.nleaf = (nt + L - 1) / L;
+  if (t.nleaf < 1)
+    t.nleaf = 1;
+  int d = 1;
+  while ((1ll << d) < t.nleaf)
+    d++;
+  t.depth = d;
+  return t;
+}
+
+constexpr int NODE_FLOATS = 16; // lo0.xyz hi0.xyz lo1.xyz hi1.xyz + 4 pad
+
+// Bottom node level: boxes of the two leaves under node n in [2^(d-1), 2^d).
+__global__ void k_bin_bottom(const float* __restrict__ tverts, const int32_t* __restrict__ tid,
+  int64_t nt, BinTree t, float* __restrict__ nodes)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // leaf slot
+  if (i >= (1ll << t.depth))
+    return;
+  float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+  const int64_t s0 = i * t.L, s1 = min(nt, s0 + t.L);
+  bool any = false;
+  for (int64_t s = s0; s < s1; s++)
+  {
+    if (tid[s] < 0)
+      continue;
+    any = true;
+    for (int k = 0; k < 3; k++)
+      for (int a = 0; a < 3; a++)
+      {
+        const float v = tverts[9 * s + 3 * k + a];
+        lo[a] = fminf(lo[a], v);
+        hi[a] = fmaxf(hi[a], v);
+      }
+  }
+  if (any)
+    for (int a = 0; a < 3; a++)
+    {
+      lo[a] = nextafterf(lo[a], -INFINITY);
+      hi[a] = nextafterf(hi[a], INFINITY);
+    }
+  const int64_t leaf_heap = (1ll << t.depth) + i;
+  float* r = nodes + (leaf_heap >> 1) * NODE_FLOATS + 6 * (leaf_heap & 1);
+  for (int a = 0; a < 3; a++)
+  {
+    r[a] = lo[a];
+    r[3 + a] = hi[a];
+  }
+}
+
+// Level k (nodes [2^k, 2^(k+1))), k < depth-1: child boxes = union of the child's record.
+__global__ void k_bin_level(int k, float* __restrict__ nodes)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (2ll << k))
+    return;
+  const int64_t child = (2ll << k) + i; // a node of level k+1
+  const float* c = nodes + child * NODE_FLOATS;
+  float* r = nodes + (child >> 1) * NODE_FLOATS + 6 * (child & 1);
+  for (int a = 0; a < 3; a++)
+  {
+    r[a] = fminf(c[a], c[6 + a]);
+    r[3 + a] = fmaxf(c[3 + a], c[9 + a]);
+  }
+}
+
+struct Search3Args
+{
+  const float* qpos;
+  int64_t nq;
+  Xf T;
+  const float* nodes;
+  BinTree tree;
+  const float* tverts;
+  const int32_t* tid;
+  int64_t nt;
+  int32_t* hint;
+  int use_hint;
+  float scene_max;
+  // contested queries
+  int32_t* cand;        // [nq][RING3]
+  uint2* tie_list;      // {query, contenders}
+  uint32_t* counters;   // [0] ties, [1] overflows
+  uint32_t* ovf_list;   // queries with more contenders than the ring holds
+  double* ovf_best;     // their screened minimum, indexed by query
+};
+
+constexpr int RING3 = 8;
+
+// fp32 lower bound of the squared distance to a box; never above the true value
+__device__ __forceinline__ float box_lb(float lox, float loy, float loz, float hix, float hiy,
+  float hiz, float xf, float yf, float zf, float eabs)
+{
+  const float dx = fmaxf(fmaxf(fmaxf(lox - xf, xf - hix), 0.f) - eabs, 0.f);
+  const float dy = fmaxf(fmaxf(fmaxf(loy - yf, yf - hiy), 0.f) - eabs, 0.f);
+  const float dz = fmaxf(fmaxf(fmaxf(loz - zf, zf - hiz), 0.f) - eabs, 0.f);
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * 0.99999952f;
+}
+
+template <int L, bool EXACT>
+__global__ __launch_bounds__(256) void k_search3(Search3Args a)
+{
+  __shared__ int32_t ring[RING3][256];
+  const int tid = threadIdx.x;
+  int64_t q = (int64_t)blockIdx.x * 256 + tid;
+  bool active;
+  if (EXACT)
+  {
+    const uint32_t novf = a.counters[1];
+    active = q < (int64_t)novf;
+    if (active)
+      q = a.ovf_list[q];
+  }
+  else
+    active = q < a.nq;
+  const int d = a.tree.depth;
+
+  d3 x = mk(0.0, 0.0, 0.0);
+  float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f;
+  double tau = 0.0, best = DBL_MAX, bound = DBL_MAX;
+  float boundf = FLT_MAX;
+  int cnt = 0;
+  int32_t hs_used = -1;  // the hinted triangle already sits in the ring
+  double ed2 = INFINITY; // EXACT mode: exact minimum so far
+  int32_t eid = 0x7fffffff, es = -1;
+
+  auto set_best = [&](double nb) {
+    const double r = sqrt(nb) + tau;
+    const double nbound = r * r;
+    if (nbound < best)
+      cnt = 0; // every older contender was above the old minimum
+    best = nb;
+    bound = nbound;
+    boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
+  };
+
+  if (active)
+  {
+    x = xform(a.T, a.qpos + 3 * q);
+    xf = (float)x.x;
+    yf = (float)x.y;
+    zf = (float)x.z;
+    const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
+    eabs = smax * 2.3841858e-07f * 1.0000002f;
+    tau = 1e-9 * (double)smax;
+    if (EXACT)
+      set_best(a.ovf_best[q]); // the final screened minimum is already known
+    else if (a.use_hint)
+    {
+      const int32_t hs = a.hint[q];
+      if (hs >= 0 && a.tid[hs] >= 0)
+      {
+        d3 P0, P1, P2;
+        load_tri(a.tverts, hs, P0, P1, P2);
+        set_best(tri_d2_screen(x, P0, P1, P2));
+        ring[0][tid] = hs;
+        cnt = 1;
+        hs_used = hs;
+      }
+    }
+  }
+
+  uint32_t n = 1, trail = 0;
+  bool done = !active, need_bt = false;
+  while (true)
+  {
+    // walk until this lane stands on a leaf whose box passed, or has nothing left
+    while (!done && (need_bt || (n >> d) == 0))
+    {
+      if (need_bt)
+      {
+        if (trail == 0)
+        {
+          done = true;
+          break;
+        }
+        const int k = 31 - __clz(trail);
+        trail ^= 1u << k;
+        const int lvl = 31 - __clz(n);
+        n = (n >> (lvl - k - 1)) ^ 1u; // the child of the level-k ancestor not yet visited
+        const float* r = a.nodes + (int64_t)(n >> 1) * NODE_FLOATS + 6 * (n & 1u);
+        const float2 b0 = *reinterpret_cast<const float2*>(r);
+        const float2 b1 = *reinterpret_cast<const float2*>(r + 2);
+        const float2 b2 = *reinterpret_cast<const float2*>(r + 4);
+        if (box_lb(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, xf, yf, zf, eabs) <= boundf)
+          need_bt = false;
+        continue;
+      }
+      const float4* p = reinterpret_cast<const float4*>(a.nodes + (int64_t)n * NODE_FLOATS);
+      const float4 u = p[0], v = p[1], w = p[2];
+      const float lb0 = box_lb(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf, eabs);
+      const float lb1 = box_lb(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf, eabs);
+      const bool ok0 = lb0 <= boundf, ok1 = lb1 <= boundf;
+      if (ok0 || ok1)
+      {
+        const uint32_t near = (ok1 && (!ok0 || lb1 < lb0)) ? 1u : 0u;
+        if (ok0 && ok1)
+          trail |= 1u << (31 - __clz(n));
+        n = 2u * n + near;
+      }
+      else
+        need_bt = true;
+    }
+    if (done)
+      break;
+
+    // leaf: screen its triangles
+    const int64_t s0 = (int64_t)(n - (1u << d)) * L;
+#pragma unroll
+    for (int t = 0; t < L; t++)
+    {
+      const int64_t s = s0 + t;
+      if (s < a.nt && a.tid[s] >= 0)
+      {
+        d3 P0, P1, P2;
+        load_tri(a.tverts, s, P0, P1, P2);
+        const double d2 = tri_d2_screen(x, P0, P1, P2);
+        if (EXACT)
+        {
+          if (d2 <= bound)
+          {
+            d3 cp;
+            double dd, w3[3];
+            const int32_t id = a.tid[s];
+            const bool up = tri_eval(x, P0, P1, P2, cp, dd, w3) && better(dd, id, ed2, eid);
+            ed2 = up ? dd : ed2;
+            eid = up ? id : eid;
+            es = up ? (int32_t)s : es;
+          }
+        }
+        else
+        {
+          if (d2 < best)
+            set_best(d2);
+          // (the hinted triangle is met again during the walk; it is in the ring already,
+          // or out of the race for good if the ring restarted since)
+          if (d2 <= bound && (int32_t)s != hs_used)
+          {
+            if (cnt < RING3)
+              ring[cnt][tid] = (int32_t)s;
+            cnt++;
+          }
+        }
+      }
+    }
+    need_bt = true;
+  }
+
+  if (EXACT)
+  {
+    if (active)
+      a.hint[q] = es;
+    return;
+  }
+
+  // settle: a single contender wins outright; 2..RING3 go to the tie list; more overflow
+  const bool tie = active && cnt >= 2 && cnt <= RING3;
+  const bool ovf = active && cnt > RING3;
+  if (active && !tie && !ovf)
+    a.hint[q] = (cnt == 1) ? ring[0][tid] : -1;
+  const int lane = tid & 63;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const unsigned long long mt = __ballot(tie);
+  if (mt)
+  {
+    const int leader = __ffsll((long long)mt) - 1;
+    uint32_t base = 0;
+    if (lane == leader)
+      base = atomicAdd(&a.counters[0], (uint32_t)__popcll(mt));
+    base = __shfl(base, leader, 64);
+    if (tie)
+    {
+      for (int i = 0; i < RING3; i++)
+        if (i < cnt)
+          a.cand[q * RING3 + i] = ring[i][tid];
+      a.tie_list[base + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
+    }
+  }
+  const unsigned long long mo = __ballot(ovf);
+  if (mo)
+  {
+    const int leader = __ffsll((long long)mo) - 1;
+    uint32_t base = 0;
+    if (lane == leader)
+      base = atomicAdd(&a.counters[1], (uint32_t)__popcll(mo));
+    base = __shfl(base, leader, 64);
+    if (ovf)
+    {
+      a.ovf_best[q] = best;
+      a.ovf_list[base + __popcll(mo & lt)] = (uint32_t)q;
+    }
+  }
+}
+
+// Contested queries: eight lanes per query, one contender per lane, exact
+// evaluation, (dist2, cell id) minimum by DPP exchanges.
+__global__ __launch_bounds__(256) void k_resolve_ties(Search3Args a)
+{
+  const uint32_t total = a.counters[0];
+  const int j = threadIdx.x & 7;
+  const uint32_t ngroups = gridDim.x * 32u;
+  for (uint32_t r = blockIdx.x * 32u + (threadIdx.x >> 3); r < total; r += ngroups)
+  {
+    const uint2 rec = a.tie_list[r];
+    const int64_t q = rec.x;
+    double d2 = INFINITY;
+    int32_t id = 0x7fffffff, s = -1;
+    if (j < (int)rec.y)
+    {
+      s = a.cand[q * RING3 + j];
+      const d3 x = xform(a.T, a.qpos + 3 * q);
+      d3 P0, P1, P2, cp;
+      double dd, w[3];
+      load_tri(a.tverts, s, P0, P1, P2);
+      if (tri_eval(x, P0, P1, P2, cp, dd, w))
+      {
+        d2 = dd;
+        id = a.tid[s];
+      }
+    }
+    group_argmin<8>(d2, id, s);
+    if (j == 0)
+      a.hint[q] = s;
+  }
+}
+
+} // namespace icpx

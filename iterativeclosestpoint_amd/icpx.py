@@ -24,7 +24,8 @@ SYMBOLS = (
     "icpx_synchronize", "icpx_set_target", "icpx_set_source", "icpx_set_shard", "icpx_get_origin",
     "icpx_accumulate", "icpx_correspond", "icpx_solve", "icpx_default_params",
     "icpx_set_allreduce", "icpx_run", "icpx_last_build_seconds", "icpx_set_group_width",
-    "icpx_reset_hints", "icpx_set_timing", "icpx_get_timing",
+    "icpx_reset_hints", "icpx_set_timing", "icpx_get_timing", "icpx_set_exhaustive",
+    "icpx_set_leaf_size",
 )
 
 
@@ -79,6 +80,8 @@ def load():
     lib.icpx_last_build_seconds.restype = dbl
     lib.icpx_set_group_width.argtypes = [vp, ci]
     lib.icpx_reset_hints.argtypes = [vp]
+    lib.icpx_set_exhaustive.argtypes = [vp, ci]
+    lib.icpx_set_leaf_size.argtypes = [vp, ci]
     lib.icpx_set_timing.argtypes = [vp, ci]
     lib.icpx_get_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl),
                                     C.POINTER(i64)]
@@ -149,6 +152,12 @@ class Context:
 
     def synchronize(self):
         _chk(load().icpx_synchronize(self._h))
+
+    def set_leaf_size(self, triangles):
+        _chk(load().icpx_set_leaf_size(self._h, int(triangles)))
+
+    def set_exhaustive(self, enable=True):
+        _chk(load().icpx_set_exhaustive(self._h, int(bool(enable))))
 
     def reset_hints(self):
         _chk(load().icpx_reset_hints(self._h))

@@ -10,7 +10,7 @@ from helpers import rel_err, sums_from_rows
 
 pytestmark = pytest.mark.gpu
 
-WIDTHS = (4, 8, 16, 32, 64)
+WIDTHS = (1, 4, 8, 16, 32, 64)
 
 
 @pytest.fixture(scope="module")
@@ -58,12 +58,14 @@ def check_rows(got, ref, allow_ties=0):
     assert np.abs(got["normal"][same] - ref["normal"][same]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("exhaustive", (False, True))
 @pytest.mark.parametrize("width", WIDTHS)
-def test_closest_point_matches_bruteforce(icpx, synth, small, width):
+def test_closest_point_matches_bruteforce(icpx, synth, small, width, exhaustive):
     c, mesh = small
     q = queries_around(synth, c["target_xyz"], c["target_tri"], 3000, seed=11 + width)
     ctx = icpx.Context(0)
     ctx.set_group_width(width)
+    ctx.set_exhaustive(exhaustive)
     ctx.set_target(c["target_xyz"], c["target_tri"])
     ctx.set_source(q)
     got = ctx.correspond(np.eye(4), step=1, max_dist=1e30)
@@ -240,9 +242,13 @@ def test_midsize_against_grid_oracle(icpx, synth, oracle):
     src = synth.apply(T, pts.astype(np.float64) + noise)
     mesh = oracle.Mesh(xyz, tri)
     ref = mesh.correspond(src, step=1, max_dist=10.0, grid=True)
-    for width in (8, 64, 0):
+    for width, exhaustive, leaf in ((8, False, 2), (64, False, 2), (0, False, 2), (4, False, 2),
+                                    (16, False, 2), (8, True, 2), (1, False, 1), (1, False, 2),
+                                    (1, False, 4)):
         ctx = icpx.Context(0)
         ctx.set_group_width(width)
+        ctx.set_exhaustive(exhaustive)
+        ctx.set_leaf_size(leaf)
         ctx.set_target(xyz, tri)
         ctx.set_source(src)
         check_rows(ctx.correspond(np.eye(4), max_dist=10.0), ref)
@@ -280,6 +286,117 @@ def test_vtkicp_surface(icpx, synth, small):
     bad.SetTarget(tgt)
     bad.Update()  # double points: error reported, matrix untouched
     assert np.array_equal(bad.GetMatrix(), np.eye(4))
+
+
+def test_golden_fixtures(icpx, synth):
+    """The committed oracle outputs (tests/golden) reproduced on the GPU."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "c1_oracle.npz"))
+    c = synth.config_c1()
+    sn = synth.vertex_normals(c["source_xyz"], c["target_tri"])
+    ctx = icpx.Context(0)
+    ctx.set_target(c["target_xyz"], c["target_tri"])
+    ctx.set_source(c["source_xyz"], sn)
+    got = ctx.correspond(g["T"], step=int(g["step"]), max_dist=float(g["max_dist"]), min_dot=0.0,
+                         use_source_normals=True)
+    ref = {k[5:]: g[k] for k in g.files if k.startswith("rows_")}
+    check_rows(got, ref)
+    for metric in (0, 1, 2):
+        sums = ctx.accumulate(metric, g["T"], step=int(g["step"]), max_dist=float(g["max_dist"]),
+                              use_source_normals=True)
+        M, n, md, rc = icpx.solve(metric, sums, ctx.origin)
+        assert rc == 0 and rel_err(M, g["solve_%d" % metric]) <= 1e-9
+        p = icpx.default_params()
+        p.metric, p.max_iterations, p.max_landmarks = metric, 50, 100
+        p.max_distance = 10.0 if metric == 0 else 0.25 * synth.diag(c["target_xyz"])
+        T, it, mean, st = ctx.run(p)
+        assert it == int(g["icp_%d_iters" % metric]) and rel_err(T, g["icp_%d" % metric]) <= 1e-6
+    cube = np.load(os.path.join(gold, "cube_oracle.npz"))
+    ctx = icpx.Context(0)
+    ctx.set_target(cube["xyz"], cube["tri"])
+    ctx.set_source(cube["q"])
+    got = ctx.correspond(np.eye(4), max_dist=100.0)
+    for k in ("cell", "dist", "closest"):
+        assert np.array_equal(got[k], cube["rows_" + k]), k
+    assert np.abs(got["normal"] - cube["rows_normal"]).max() <= 1e-6
+
+
+def test_degenerate_and_duplicate_triangles(icpx, synth, oracle):
+    """Zero-area triangles are skipped (as the locator skips them); duplicated triangles tie
+    exactly and the smaller cell id wins; unwelded seams tie across different point ids."""
+    xyz, tri = synth.bumpy_torus(24, 12)
+    nv = len(xyz)
+    xyz2 = np.concatenate([xyz, xyz[:50]])                      # unwelded copies of 50 points
+    extra = np.array([[0, 0, 1], [5, 5, 5], [3, 4, 3]], np.int32)  # zero-area
+    dup = tri[:40].copy()                                       # exact duplicates (ids nt+3..)
+    seam = tri[40:80].copy()
+    seam[seam < 50] += nv                                       # same geometry, other point ids
+    tri2 = np.ascontiguousarray(np.concatenate([extra, tri, dup, seam]))
+    mesh = oracle.Mesh(xyz2, tri2)
+    q = queries_around(synth, xyz, tri, 2000, seed=77)
+    for width, exhaustive in ((8, False), (4, False), (64, False), (8, True), (1, False)):
+        ctx = icpx.Context(0)
+        ctx.set_group_width(width)
+        ctx.set_exhaustive(exhaustive)
+        ctx.set_target(xyz2, tri2)
+        ctx.set_source(q)
+        check_rows(ctx.correspond(np.eye(4), max_dist=1e30),
+                   mesh.correspond(q, max_dist=1e30, grid=False))
+
+
+def test_many_way_ties(icpx, synth, oracle):
+    """A 40-triangle fan: above the apex every triangle is exactly equidistant, which is
+    more contenders than the kernels' tie rings hold; the smallest cell id must win."""
+    k = 40
+    ang = np.arange(k) * (2 * np.pi / k)
+    xyz = np.concatenate([[[0, 0, 1]], np.stack([np.cos(ang), np.sin(ang), 0 * ang], -1)])
+    xyz = xyz.astype(np.float32)
+    tri = np.array([[0, 1 + i, 1 + (i + 1) % k] for i in range(k)], np.int32)
+    tri = np.roll(tri, 7, axis=0)                     # winner is not simply the first visited
+    q = np.array([[0, 0, 2], [0, 0, 1], [0, 0, 1.5], [0.01, 0, 2], [0.5, 0.5, 0.5], [2, 0, 0],
+                  [0, 0, -1], [1, 0, 0]], np.float32)
+    q = np.concatenate([q, queries_around(synth, xyz, tri, 300, seed=9)])
+    mesh = oracle.Mesh(xyz, tri)
+    ref = mesh.correspond(q, max_dist=1e30, grid=False)
+    assert ref["cell"][0] == 0 and ref["kind"][0] == 2
+    for width in (1, 4, 8, 64):
+        ctx = icpx.Context(0)
+        ctx.set_group_width(width)
+        ctx.set_target(xyz, tri)
+        ctx.set_source(q)
+        check_rows(ctx.correspond(np.eye(4), max_dist=1e30), ref)
+        check_rows(ctx.correspond(np.eye(4), max_dist=1e30), ref)   # hinted pass
+
+
+def test_random_tiny_meshes_with_duplicates(icpx, oracle):
+    """Hundreds of tiny random triangle soups (shared points, exact duplicate and permuted
+    triangles, queries on the points themselves): every kernel variant returns the oracle's
+    (dist2, cell id) minimum."""
+    rng = np.random.default_rng(1)
+    for trial in range(120):
+        nvp = rng.integers(4, 9)
+        xyz = rng.uniform(-1, 1, (nvp, 3)).astype(np.float32)
+        ntr = rng.integers(2, 9)
+        tri = np.array([rng.choice(nvp, 3, replace=False) for _ in range(ntr)], np.int32)
+        ndup = rng.integers(0, 4)
+        if ndup:
+            tri = np.concatenate([tri, tri[rng.integers(0, ntr, ndup)]])
+        tri = np.ascontiguousarray(tri[rng.permutation(len(tri))])
+        q = np.concatenate([xyz, rng.uniform(-1.5, 1.5, (6, 3)).astype(np.float32)])
+        ref = oracle.Mesh(xyz, tri).correspond(q, max_dist=1e30, grid=False)
+        for width, leaf in ((1, 1), (1, 2), (1, 4), (8, 2), (64, 2)):
+            if trial % 3 and width != 1:
+                continue
+            ctx = icpx.Context(0)
+            ctx.set_group_width(width)
+            ctx.set_leaf_size(leaf)
+            ctx.set_target(xyz, tri)
+            ctx.set_source(q)
+            got = ctx.correspond(np.eye(4), max_dist=1e30)
+            assert np.array_equal(got["cell"], ref["cell"]), (trial, width, leaf)
+            assert np.array_equal(got["dist"], ref["dist"])
+            ctx.close()
 
 
 def test_abi_rejects_bad_input(icpx):

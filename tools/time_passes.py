@@ -1,0 +1,55 @@
+"""Development aid: per-pass kernel times of the search on a workload, for a few
+characteristic situations (cold pass at the initial pose, hinted pass at the same pose,
+hinted pass at the registered pose)."""
+import argparse
+import sys
+import os
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from iterativeclosestpoint_amd import icpx, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--widths", default="1,4,8")
+    ap.add_argument("--leaf", type=int, default=2)
+    ap.add_argument("--exhaustive", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    c = {"c3": synth.config_c3, "c4": synth.config_c4}[a.workload]()
+    metric = c["metric"]
+    Tinv = np.linalg.inv(c["truth"])
+    for w in [int(x) for x in a.widths.split(",")]:
+        ctx = icpx.Context(0)
+        ctx.set_group_width(w)
+        ctx.set_exhaustive(a.exhaustive)
+        ctx.set_leaf_size(a.leaf)
+        ctx.set_target(c["target_xyz"], c["target_tri"])
+        ctx.set_source(c["source_xyz"], c["source_normals"])
+        ctx.accumulate(metric, np.eye(4), 1, c["max_dist"])  # builds tree, sorts queries
+
+        def timed(T, reset):
+            ts = []
+            for _ in range(a.reps):
+                if reset:
+                    ctx.reset_hints()
+                ctx.set_timing(True)
+                ctx.accumulate(metric, T, 1, c["max_dist"])
+                s_ms, s_n, f_ms, f_n = ctx.get_timing()
+                ts.append(s_ms)
+            return min(ts), float(np.median(ts))
+        cold = timed(np.eye(4), True)
+        hot0 = timed(np.eye(4), False)
+        ctx.accumulate(metric, Tinv, 1, c["max_dist"])
+        hot1 = timed(Tinv, False)
+        cold1 = timed(Tinv, True)
+        print("width %2d  cold@start %.3f  hinted@start %.3f  hinted@registered %.3f  "
+              "cold@registered %.3f ms (min)  build %.1f ms" %
+              (w, cold[0], hot0[0], hot1[0], cold1[0], 1e3 * ctx.build_seconds), flush=True)
+        ctx.close()
+
+
+if __name__ == "__main__":
+    main()
