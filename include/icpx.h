@@ -178,6 +178,17 @@ extern "C"
   /* Triangles per leaf of the lane-per-query kernel's tree: 1, 2 (default) or 4. */
   int icpx_set_leaf_size(icpx_ctx* ctx, int triangles);
 
+  /* Hinted shortcut of the lane-per-query path: 1 (default) = when the previous pass left
+   * a small residual, queries close to their previous winner test only the leaves near
+   * that winner's leaf (precomputed neighbour lists) instead of walking the tree; the
+   * rest still walk it.  0 = always walk the tree.  Same results. */
+  int icpx_set_local(icpx_ctx* ctx, int enable);
+
+  /* Lane-per-query kernel scheduling: 1 (default) = a resident grid whose lanes draw
+   * queries from a pool as they finish; 0 = one query per lane for the lifetime of a
+   * wavefront.  Same results. */
+  int icpx_set_persistent(icpx_ctx* ctx, int enable);
+
   /* Search kernel selection.  0 (default): the production kernel, which screens
    * triangles with a short fp64 routine and evaluates only near-ties (within
    * 1e-9 x the largest coordinate of the minimum) with the reference's exact
@@ -185,6 +196,13 @@ extern "C"
    * triangle exactly.  Both return the same winners; the second exists as a
    * cross-check. */
   int icpx_set_exhaustive(icpx_ctx* ctx, int enable);
+
+  /* Diagnostic: copy an internal array to the host.  what = 0: winners of the last search
+   * pass (Morton positions of triangles, int32 per query of this shard); 1: Morton
+   * position -> cell id (int32 per triangle, -1-id for a degenerate one); 2: {ties,
+   * overflows} counted by the last lane-per-query pass (2 x uint32); 4: {shortcut passes,
+   * tree-only passes, neighbour-list builds, list radius x 1e9, list entries} (5 x int64). */
+  int icpx_debug_dump(icpx_ctx* ctx, int what, void* out, int64_t count);
 
   /* Forget the winners of the previous search pass.  A pass normally starts each
    * query from the triangle that won last time (only as an upper bound: results

@@ -9,6 +9,7 @@
 #include "query.hpp"
 #include "search2.hpp"
 #include "search3.hpp"
+#include "local.hpp"
 #include "tables.hpp"
 
 #include <chrono>
@@ -77,6 +78,7 @@ struct icpx_ctx
   int32_t* d_tri = nullptr;
   float* d_tverts = nullptr;
   int32_t* d_tid = nullptr;
+  uint64_t* d_tcodes = nullptr; // sorted Morton codes of the triangles
   float *d_fn = nullptr, *d_en = nullptr, *d_vn = nullptr;
   Box3 box;
   double origin[3] = { 0, 0, 0 };
@@ -84,6 +86,22 @@ struct icpx_ctx
   Heap heaps[5];  // group kernel's heap-ordered trees
   Bin bins[3];    // lane-per-query kernel's binary trees (1, 2, 4 triangles per leaf)
   int leaf_size = 2;
+  int persistent = 1;
+  int num_cus = 256;
+  // hinted shortcut: per-leaf neighbour lists for one radius, and the residual statistics
+  // of the previous pass that choose the radius
+  int use_local = 1;
+  int nbr_L = 0;
+  float nbr_eps = 0.f;
+  float nbr_disabled_eps = INFINITY; // lists at this radius or above were too long
+  uint32_t* d_noff = nullptr;
+  int32_t* d_nbr = nullptr;
+  uint32_t* d_fallback = nullptr;
+  double* h_stat = nullptr; // pinned {n, sum |s-t|} of the last accumulate pass
+  hipEvent_t ev_stat = nullptr;
+  bool stat_pending = false, stat_valid = false;
+  double last_mean = 0.0;
+  int64_t local_passes = 0, tree_passes = 0, nbr_builds = 0, nbr_total = 0;
   // lane-per-query kernel's tie bookkeeping, sized for q3_cap queries
   int64_t q3_cap = 0;
   int32_t* d_cand = nullptr;
@@ -255,6 +273,7 @@ static void free_target(icpx_ctx* c)
   dev_free(&c->d_tri);
   dev_free(&c->d_tverts);
   dev_free(&c->d_tid);
+  dev_free(&c->d_tcodes);
   dev_free(&c->d_fn);
   dev_free(&c->d_en);
   dev_free(&c->d_vn);
@@ -273,6 +292,12 @@ static void free_target(icpx_ctx* c)
     dev_free(&t.nodes);
     t.built = false;
   }
+  dev_free(&c->d_noff);
+  dev_free(&c->d_nbr);
+  c->nbr_eps = 0.f;
+  c->nbr_L = 0;
+  c->nbr_disabled_eps = INFINITY;
+  c->stat_valid = false;
   c->nv = c->nt = 0;
 }
 static void free_queries(icpx_ctx* c)
@@ -286,6 +311,7 @@ static void free_queries(icpx_ctx* c)
   dev_free(&c->d_counters);
   dev_free(&c->d_ovf_list);
   dev_free(&c->d_ovf_best);
+  dev_free(&c->d_fallback);
   c->q_cap = 0;
   c->q3_cap = 0;
   c->prep_step = -1;
@@ -337,6 +363,11 @@ extern "C" int icpx_create(icpx_ctx** out, int device)
   if (!c)
     return fail(ICPX_E_NOMEM, "icpx_create: out of host memory");
   c->device = device;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      c->num_cus = prop.multiProcessorCount;
+  }
   hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess)
   {
@@ -349,6 +380,10 @@ extern "C" int icpx_create(icpx_ctx** out, int device)
     rc = dev_alloc(&c->d_sums, ICPX_NSUMS);
   if (!rc && hipHostMalloc((void**)&c->h_sums, sizeof(double) * ICPX_NSUMS) != hipSuccess)
     rc = fail(ICPX_E_NOMEM, "hipHostMalloc failed");
+  if (!rc && hipHostMalloc((void**)&c->h_stat, sizeof(double) * 2) != hipSuccess)
+    rc = fail(ICPX_E_NOMEM, "hipHostMalloc failed");
+  if (!rc && hipEventCreateWithFlags(&c->ev_stat, hipEventDisableTiming) != hipSuccess)
+    rc = fail(ICPX_E_HIP, "hipEventCreate failed");
   if (rc)
   {
     icpx_destroy(c);
@@ -374,6 +409,10 @@ extern "C" void icpx_destroy(icpx_ctx* c)
   dev_free(&c->d_sums);
   if (c->h_sums)
     (void)hipHostFree(c->h_sums);
+  if (c->h_stat)
+    (void)hipHostFree(c->h_stat);
+  if (c->ev_stat)
+    (void)hipEventDestroy(c->ev_stat);
   resolve_timing(c);
   for (auto e : c->free_events)
     (void)hipEventDestroy(e);
@@ -470,6 +509,13 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
     src = c->d_counters;
     bytes = sizeof(uint32_t) * 2;
   }
+  else if (what == 4)
+  {
+    int64_t v[5] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
+      c->nbr_total };
+    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 5));
+    return ICPX_OK;
+  }
   else if (what == 3 && c->d_ovf_best)
   {
     src = c->d_ovf_best;
@@ -491,6 +537,22 @@ extern "C" int icpx_set_leaf_size(icpx_ctx* c, int triangles)
   return ICPX_OK;
 }
 
+extern "C" int icpx_set_local(icpx_ctx* c, int enable)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  c->use_local = enable ? 1 : 0;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_persistent(icpx_ctx* c, int enable)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  c->persistent = enable ? 1 : 0;
+  return ICPX_OK;
+}
+
 extern "C" int icpx_set_exhaustive(icpx_ctx* c, int enable)
 {
   if (!c)
@@ -504,6 +566,8 @@ extern "C" int icpx_reset_hints(icpx_ctx* c)
   if (!c)
     return fail(ICPX_E_INVALID, "null context");
   c->hint_valid = false;
+  c->stat_valid = false;
+  c->stat_pending = false;
   return ICPX_OK;
 }
 
@@ -628,6 +692,9 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
     c->d_xyz, c->d_tri, which ? v1 : v0, nt, c->d_tverts, c->d_tid);
   k_flag_degenerate<<<nblk(nt, 256), 256, 0, st>>>(c->d_tverts, nt, c->d_tid);
   hipError_t e = hipGetLastError();
+  if (e == hipSuccess && dev_alloc(&c->d_tcodes, nt) == ICPX_OK)
+    e = hipMemcpyAsync(
+      c->d_tcodes, which ? k1 : k0, sizeof(uint64_t) * nt, hipMemcpyDeviceToDevice, st);
   if (e == hipSuccess)
     e = hipStreamSynchronize(st);
   drop_sort();
@@ -899,14 +966,93 @@ static int ensure_bin(icpx_ctx* c, int L)
 }
 
 template <int L>
-static void launch_search3(const Search3Args& a, unsigned grid, hipStream_t st)
+static void launch_search3(const Search3Args& a, unsigned grid, unsigned pgrid, hipStream_t st)
 {
-  k_search3<L, false><<<grid, 256, 0, st>>>(a);
+  if (pgrid)
+    k_search3p<L><<<pgrid, 256, 0, st>>>(a);
+  else
+    k_search3<L, false><<<grid, 256, 0, st>>>(a);
   unsigned rgrid = grid / 8 + 1;
   if (rgrid > 2048)
     rgrid = 2048;
   k_resolve_ties<<<rgrid, 256, 0, st>>>(a);
   k_search3<L, true><<<grid, 256, 0, st>>>(a);
+}
+
+// Neighbour lists of every leaf for radius eps (see local.hpp).  Returns ICPX_OK with
+// c->nbr_eps == 0 when the lists would be too long to pay off.
+static int build_nbr(icpx_ctx* c, const Bin& b, int L, float eps)
+{
+  hipStream_t st = c->stream;
+  dev_free(&c->d_noff);
+  dev_free(&c->d_nbr);
+  c->nbr_eps = 0.f;
+  const int64_t nl = b.t.nleaf;
+  uint32_t* scr = nullptr;
+  ALLOC(c->d_noff, nl + 1);
+  int rc = dev_alloc(&scr, scan_scratch_words(nl + 1));
+  if (rc)
+    return rc;
+  const float eps2 = nextafterf(eps * eps, INFINITY);
+  (void)hipMemsetAsync(c->d_noff + nl, 0, sizeof(uint32_t), st);
+  k_nbr<false><<<nblk(nl, 256), 256, 0, st>>>(b.nodes, b.t, eps2, c->d_noff, nullptr, nullptr);
+  exclusive_scan(c->d_noff, c->d_noff, nl + 1, scr, st);
+  uint32_t total = 0;
+  hipError_t e = hipMemcpyAsync(&total, c->d_noff + nl, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  dev_free(&scr);
+  if (e != hipSuccess)
+    return fail(ICPX_E_HIP, "neighbour count failed: %s", hipGetErrorString(e));
+  c->nbr_builds++;
+  c->nbr_total = total;
+  if ((double)total > 48.0 * (double)nl)
+  {
+    c->nbr_disabled_eps = eps; // too many neighbours at this radius: the tree walk is better
+    dev_free(&c->d_noff);
+    return ICPX_OK;
+  }
+  ALLOC(c->d_nbr, (int64_t)total + 1);
+  k_nbr<true><<<nblk(nl, 256), 256, 0, st>>>(b.nodes, b.t, eps2, nullptr, c->d_noff, c->d_nbr);
+  LAUNCHCHK();
+  c->nbr_eps = eps;
+  c->nbr_L = L;
+  return ICPX_OK;
+}
+
+// Radius policy: lists should cover queries up to four times the previous pass's mean
+// residual (2r <= eps), and are rebuilt when the residual leaves the band they suit.
+static int prepare_local(icpx_ctx* c, const Bin& b, int L, bool* use)
+{
+  *use = false;
+  if (!c->use_local || !c->hint_valid)
+    return ICPX_OK;
+  if (c->stat_pending)
+  {
+    HIPCHK(hipEventSynchronize(c->ev_stat));
+    c->stat_pending = false;
+    c->stat_valid = c->h_stat[0] > 0.0;
+    if (c->stat_valid)
+      c->last_mean = c->h_stat[1] / c->h_stat[0];
+  }
+  if (!c->stat_valid)
+    return ICPX_OK;
+  const double floor_eps = 256.0 * 2.3841858e-07 * (double)c->scene_max;
+  const double mean = c->last_mean;
+  const bool fits = c->nbr_eps > 0.f && c->nbr_L == L &&
+    (double)c->nbr_eps >= std::fmax(4.0 * mean, floor_eps * 0.999) &&
+    (double)c->nbr_eps <= std::fmax(64.0 * mean, floor_eps * 1.001);
+  if (!fits)
+  {
+    const float eps = (float)std::fmax(8.0 * mean, floor_eps);
+    if (eps >= 0.5f * c->nbr_disabled_eps)
+      return ICPX_OK;
+    int rc = build_nbr(c, b, L, eps);
+    if (rc)
+      return rc;
+  }
+  *use = c->nbr_eps > 0.f;
+  return ICPX_OK;
 }
 
 static int run_search3(icpx_ctx* c, const double T[16])
@@ -919,9 +1065,10 @@ static int run_search3(icpx_ctx* c, const double T[16])
   {
     ALLOC(c->d_cand, c->nq * RING3);
     ALLOC(c->d_tie_list, c->nq);
-    ALLOC(c->d_counters, 2);
+    ALLOC(c->d_counters, 4);
     ALLOC(c->d_ovf_list, c->nq);
     ALLOC(c->d_ovf_best, c->nq);
+    ALLOC(c->d_fallback, c->nq);
     c->q3_cap = c->nq;
   }
   const Bin& b = c->bins[(L == 1) ? 0 : (L == 2) ? 1 : 2];
@@ -937,21 +1084,55 @@ static int run_search3(icpx_ctx* c, const double T[16])
   a.hint = c->d_hint;
   a.use_hint = c->hint_valid ? 1 : 0;
   a.scene_max = c->scene_max;
+  a.tcodes = c->d_tcodes;
+  a.box = c->box;
   a.cand = c->d_cand;
   a.tie_list = c->d_tie_list;
   a.counters = c->d_counters;
   a.ovf_list = c->d_ovf_list;
   a.ovf_best = c->d_ovf_best;
+  a.qlist = nullptr;
   hipStream_t st = c->stream;
   const unsigned grid = nblk(c->nq, 256);
+  bool use_local = false;
+  rc = prepare_local(c, b, L, &use_local);
+  if (rc)
+    return rc;
   ScopedTimer tm(c, 0);
-  HIPCHK(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(uint32_t), st));
-  if (L == 1)
-    launch_search3<1>(a, grid, st);
-  else if (L == 2)
-    launch_search3<2>(a, grid, st);
+  HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), st));
+  if (use_local)
+  {
+    LocalArgs la;
+    la.s = a;
+    la.noff = c->d_noff;
+    la.nbr = c->d_nbr;
+    la.eps = c->nbr_eps;
+    la.fallback = c->d_fallback;
+    if (L == 1)
+      k_search_local<1><<<grid, 256, 0, st>>>(la);
+    else if (L == 2)
+      k_search_local<2><<<grid, 256, 0, st>>>(la);
+    else
+      k_search_local<4><<<grid, 256, 0, st>>>(la);
+    a.qlist = c->d_fallback; // the tree kernel serves what is left
+    c->local_passes++;
+  }
   else
-    launch_search3<4>(a, grid, st);
+    c->tree_passes++;
+  // persistent lanes: as many wavefronts as stay resident, each drawing queries from a pool
+  unsigned pgrid = 0;
+  if (c->persistent || use_local)
+  {
+    pgrid = (unsigned)c->num_cus * 5u;
+    if (pgrid > grid)
+      pgrid = grid;
+  }
+  if (L == 1)
+    launch_search3<1>(a, grid, pgrid, st);
+  else if (L == 2)
+    launch_search3<2>(a, grid, pgrid, st);
+  else
+    launch_search3<4>(a, grid, pgrid, st);
   LAUNCHCHK();
   c->hint_valid = true;
   return ICPX_OK;
@@ -1131,6 +1312,10 @@ extern "C" int icpx_accumulate(icpx_ctx* c, int metric, const double T[16], int6
     }
     k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst);
     LAUNCHCHK();
+    // residual statistics for the next pass's choice of search radius
+    HIPCHK(hipMemcpyAsync(c->h_stat, dst, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(c->ev_stat, st));
+    c->stat_pending = true;
   }
   if (sums_host)
   {

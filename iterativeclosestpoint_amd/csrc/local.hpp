@@ -1,0 +1,266 @@
+// local.hpp — the hinted shortcut: no tree walk when the previous winner is close.
+//
+// If a query sits within r of its previous winner h (a triangle of leaf l_h), every
+// triangle within r of the query lies in a leaf whose box is within 2r of l_h's
+// box (both closest points are within r of the query).  So for every leaf the
+// list of leaves whose boxes come within eps of it is built once (k_nbr_count /
+// k_nbr_fill: one lane per leaf, a fixed-radius walk of the binary tree), and a
+// hinted query with 2r <= eps only tests that list: a flat loop of box tests with
+// the same trip count for neighbouring lanes, then the usual screening of the few
+// leaves that pass.  Queries whose r is too large (or that have no usable hint)
+// are appended to a list that the tree kernel then serves.  The contenders found
+// are the same as the tree walk's, so the winner is too.
+//
+// eps follows the registration: the host asks for four times the mean residual of
+// the previous pass and rebuilds the lists when that leaves the band they cover.
+#pragma once
+#include "search3.hpp"
+
+namespace icpx
+{
+
+// fp32 lower bound of the squared distance between two boxes (records of six floats)
+__device__ __forceinline__ float box_box_lb(const float* __restrict__ A, float b0, float b1,
+  float b2, float b3, float b4, float b5)
+{
+  const float gx = fmaxf(fmaxf(A[0] - b3, b0 - A[3]), 0.f) * 0.99999976f;
+  const float gy = fmaxf(fmaxf(A[1] - b4, b1 - A[4]), 0.f) * 0.99999976f;
+  const float gz = fmaxf(fmaxf(A[2] - b5, b2 - A[5]), 0.f) * 0.99999976f;
+  return __builtin_fmaf(gz, gz, __builtin_fmaf(gy, gy, gx * gx)) * 0.99999952f;
+}
+
+// Counting and filling both stop one past this many neighbours.  A leaf whose list is
+// cut short (a box stretched across a jump of the Morton curve, or a radius that is too
+// large for the mesh) is recognised by its length and its queries take the tree walk.
+constexpr uint32_t NBR_CAP = 96;
+
+// One lane per leaf: all leaves whose boxes come within sqrt(eps2) of it.
+// FILL = false counts them, FILL = true writes them at off[leaf].
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_nbr(const float* __restrict__ nodes, BinTree t,
+  float eps2, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+  int32_t* __restrict__ nbr)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= t.nleaf)
+    return;
+  const int d = t.depth;
+  const uint32_t self = (1u << d) + (uint32_t)i;
+  float A[6];
+  {
+    const float* r = nodes + (int64_t)(self >> 1) * NODE_FLOATS + 6 * (self & 1u);
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      A[k] = r[k];
+  }
+  uint32_t count = 0;
+  const uint32_t base = FILL ? off[i] : 0u;
+  if (A[0] <= A[3]) // not an empty box
+  {
+    uint32_t n = 1, trail = 0;
+    bool need_bt = false;
+    while (true)
+    {
+      if (need_bt)
+      {
+        if (trail == 0)
+          break;
+        const int k = 31 - __clz(trail);
+        trail ^= 1u << k;
+        const int lvl = 31 - __clz(n);
+        n = (n >> (lvl - k - 1)) ^ 1u;
+        need_bt = false;
+      }
+      if (n >> d)
+      {
+        if (FILL)
+          nbr[base + count] = (int32_t)(n - (1u << d));
+        count++;
+        if (count > NBR_CAP)
+          break;
+        need_bt = true;
+        continue;
+      }
+      const float4* p = reinterpret_cast<const float4*>(nodes + (int64_t)n * NODE_FLOATS);
+      const float4 u = p[0], v = p[1], w = p[2];
+      const bool ok0 = box_box_lb(A, u.x, u.y, u.z, u.w, v.x, v.y) <= eps2;
+      const bool ok1 = box_box_lb(A, v.z, v.w, w.x, w.y, w.z, w.w) <= eps2;
+      if (ok0 || ok1)
+      {
+        if (ok0 && ok1)
+          trail |= 1u << (31 - __clz(n));
+        n = 2u * n + (ok0 ? 0u : 1u);
+      }
+      else
+        need_bt = true;
+    }
+  }
+  if (!FILL)
+    cnt[i] = count;
+}
+
+struct LocalArgs
+{
+  Search3Args s;        // the tree kernel's arguments (queries, tree, triangles, tie lists)
+  const uint32_t* noff; // neighbour lists, CSR over leaves
+  const int32_t* nbr;
+  float eps;            // radius the lists were built for
+  uint32_t* fallback;   // queries left to the tree kernel; their count is counters[3]
+};
+
+template <int L>
+__global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
+{
+  const Search3Args& a = la.s;
+  __shared__ int32_t ring[RING3][256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int64_t q = (int64_t)blockIdx.x * 256 + tid;
+  const bool active = q < a.nq;
+  const int d = a.tree.depth;
+
+  d3 x = mk(0.0, 0.0, 0.0);
+  float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f;
+  double tau = 0.0, best = DBL_MAX, bound = DBL_MAX;
+  float boundf = FLT_MAX;
+  int cnt = 0;
+  int32_t hs = -1;
+  bool local = false;
+
+  auto set_best = [&](double nb) {
+    const double r = sqrt(nb) + tau;
+    const double nbound = r * r;
+    if (nbound < best)
+      cnt = 0;
+    best = nb;
+    bound = nbound;
+    boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
+  };
+
+  uint32_t e = 0, eend = 0;
+  if (active)
+  {
+    x = xform(a.T, a.qpos + 3 * q);
+    xf = (float)x.x;
+    yf = (float)x.y;
+    zf = (float)x.z;
+    const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
+    eabs = smax * 2.3841858e-07f * 1.0000002f;
+    tau = 1e-9 * (double)smax;
+    hs = a.hint[q];
+    if (hs >= 0 && a.tid[hs] >= 0)
+    {
+      d3 P0, P1, P2;
+      load_tri(a.tverts, hs, P0, P1, P2);
+      set_best(tri_d2_screen(x, P0, P1, P2));
+      // every contender is within r of the query, hence within 2r of the hinted triangle
+      const double r = sqrt(best) + tau;
+      local = 2.0 * r * 1.000001 + 4.0 * (double)eabs <= (double)la.eps;
+      if (local)
+      {
+        const int64_t leaf = hs / L;
+        e = la.noff[leaf];
+        eend = la.noff[leaf + 1];
+        local = eend - e <= NBR_CAP; // a longer list was cut short
+      }
+      if (local)
+      {
+        ring[0][tid] = hs;
+        cnt = 1;
+      }
+    }
+  }
+  // queries this kernel cannot settle go to the tree kernel
+  {
+    const bool fb = active && !local;
+    const unsigned long long mf = __ballot(fb);
+    if (mf)
+    {
+      const int leader = __ffsll((long long)mf) - 1;
+      uint32_t base = 0;
+      if (lane == leader)
+        base = atomicAdd(&a.counters[3], (uint32_t)__popcll(mf));
+      base = __shfl(base, leader, 64);
+      if (fb)
+        la.fallback[base + __popcll(mf & lt)] = (uint32_t)q;
+    }
+  }
+
+  int32_t cur = -1;
+  while (true)
+  {
+    // next neighbouring leaf whose box is within the bound
+    while (local && cur < 0 && e < eend)
+    {
+      const int32_t m = la.nbr[e++];
+      const uint32_t heap = (1u << d) + (uint32_t)m;
+      const float* r = a.nodes + (int64_t)(heap >> 1) * NODE_FLOATS + 6 * (heap & 1u);
+      const float2 b0 = *reinterpret_cast<const float2*>(r);
+      const float2 b1 = *reinterpret_cast<const float2*>(r + 2);
+      const float2 b2 = *reinterpret_cast<const float2*>(r + 4);
+      if (box_lb(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, xf, yf, zf, eabs) <= boundf)
+        cur = m;
+    }
+    if (cur < 0)
+      break;
+    const int64_t s0 = (int64_t)cur * L;
+#pragma unroll
+    for (int t = 0; t < L; t++)
+    {
+      const int64_t s = s0 + t;
+      if (s < a.nt && a.tid[s] >= 0 && (int32_t)s != hs)
+      {
+        d3 P0, P1, P2;
+        load_tri(a.tverts, s, P0, P1, P2);
+        const double d2 = tri_d2_screen(x, P0, P1, P2);
+        if (d2 < best)
+          set_best(d2);
+        if (d2 <= bound)
+        {
+          if (cnt < RING3)
+            ring[cnt][tid] = (int32_t)s;
+          cnt++;
+        }
+      }
+    }
+    cur = -1;
+  }
+
+  // settle (as the tree kernel does)
+  const bool tie = local && cnt >= 2 && cnt <= RING3;
+  const bool ovf = local && cnt > RING3;
+  if (local && !tie && !ovf)
+    a.hint[q] = (cnt == 1) ? ring[0][tid] : -1;
+  const unsigned long long mt = __ballot(tie);
+  if (mt)
+  {
+    const int leader = __ffsll((long long)mt) - 1;
+    uint32_t base = 0;
+    if (lane == leader)
+      base = atomicAdd(&a.counters[0], (uint32_t)__popcll(mt));
+    base = __shfl(base, leader, 64);
+    if (tie)
+    {
+      for (int i = 0; i < RING3; i++)
+        if (i < cnt)
+          a.cand[q * RING3 + i] = ring[i][tid];
+      a.tie_list[base + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
+    }
+  }
+  const unsigned long long mo = __ballot(ovf);
+  if (mo)
+  {
+    const int leader = __ffsll((long long)mo) - 1;
+    uint32_t base = 0;
+    if (lane == leader)
+      base = atomicAdd(&a.counters[1], (uint32_t)__popcll(mo));
+    base = __shfl(base, leader, 64);
+    if (ovf)
+    {
+      a.ovf_best[q] = best;
+      a.ovf_list[base + __popcll(mo & lt)] = (uint32_t)q;
+    }
+  }
+}
+
+} // namespace icpx

@@ -117,12 +117,15 @@ struct Search3Args
   int32_t* hint;
   int use_hint;
   float scene_max;
+  const uint64_t* tcodes; // Morton codes of the triangles in sorted order (cold-start seed), or null
+  Box3 box;
   // contested queries
   int32_t* cand;        // [nq][RING3]
   uint2* tie_list;      // {query, contenders}
-  uint32_t* counters;   // [0] ties, [1] overflows
+  uint32_t* counters;   // [0] ties, [1] overflows, [2] next query of the pool
   uint32_t* ovf_list;   // queries with more contenders than the ring holds
   double* ovf_best;     // their screened minimum, indexed by query
+  const uint32_t* qlist; // persistent kernel: serve only these queries (count in counters[3]), or null
 };
 
 constexpr int RING3 = 8;
@@ -185,9 +188,25 @@ __global__ __launch_bounds__(256) void k_search3(Search3Args a)
     tau = 1e-9 * (double)smax;
     if (EXACT)
       set_best(a.ovf_best[q]); // the final screened minimum is already known
-    else if (a.use_hint)
+    else
     {
-      const int32_t hs = a.hint[q];
+      int32_t hs = a.use_hint ? a.hint[q] : -1;
+      if (hs < 0 && a.tcodes)
+      {
+        // cold start: the triangle whose centroid follows the query along the Morton curve
+        // gives a first bound, so the walk starts as tight as a hinted one
+        const uint64_t code = morton63(xf, yf, zf, a.box.lo, a.box.inv);
+        int64_t lo = 0, hi = a.nt; // first position with tcodes[pos] >= code
+        while (lo < hi)
+        {
+          const int64_t mid = (lo + hi) >> 1;
+          if (a.tcodes[mid] < code)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        hs = (int32_t)min(lo, a.nt - 1);
+      }
       if (hs >= 0 && a.tid[hs] >= 0)
       {
         d3 P0, P1, P2;
@@ -200,46 +219,61 @@ __global__ __launch_bounds__(256) void k_search3(Search3Args a)
     }
   }
 
+  // One step of the walk is a single code path for every lane: (1) a lane that has to
+  // back up turns to the deepest ancestor still owed its other child (pure register
+  // arithmetic; only for a pending *leaf* is the bound known, kept in lbleaf, because at
+  // most one leaf-level entry is ever pending); (2) a lane standing on a node reads its
+  // record and tests both children.  A far child that is an inner node is entered without
+  // re-testing it: if it went stale its own visit rejects both children at once.
   uint32_t n = 1, trail = 0;
-  bool done = !active, need_bt = false;
+  float lbleaf = 0.f;
+  bool done = !active, need_bt = false, atleaf = false;
   while (true)
   {
-    // walk until this lane stands on a leaf whose box passed, or has nothing left
-    while (!done && (need_bt || (n >> d) == 0))
+    while (!done && !atleaf)
     {
       if (need_bt)
       {
         if (trail == 0)
-        {
           done = true;
-          break;
-        }
-        const int k = 31 - __clz(trail);
-        trail ^= 1u << k;
-        const int lvl = 31 - __clz(n);
-        n = (n >> (lvl - k - 1)) ^ 1u; // the child of the level-k ancestor not yet visited
-        const float* r = a.nodes + (int64_t)(n >> 1) * NODE_FLOATS + 6 * (n & 1u);
-        const float2 b0 = *reinterpret_cast<const float2*>(r);
-        const float2 b1 = *reinterpret_cast<const float2*>(r + 2);
-        const float2 b2 = *reinterpret_cast<const float2*>(r + 4);
-        if (box_lb(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, xf, yf, zf, eabs) <= boundf)
+        else
+        {
+          const int k = 31 - __clz(trail);
+          trail ^= 1u << k;
+          const int lvl = 31 - __clz(n);
+          n = (n >> (lvl - k - 1)) ^ 1u; // the child of the level-k ancestor not yet visited
           need_bt = false;
-        continue;
+          if (k == d - 1)
+          {
+            if (lbleaf > boundf)
+              need_bt = true; // went stale meanwhile
+            else
+              atleaf = true;
+          }
+        }
       }
-      const float4* p = reinterpret_cast<const float4*>(a.nodes + (int64_t)n * NODE_FLOATS);
-      const float4 u = p[0], v = p[1], w = p[2];
-      const float lb0 = box_lb(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf, eabs);
-      const float lb1 = box_lb(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf, eabs);
-      const bool ok0 = lb0 <= boundf, ok1 = lb1 <= boundf;
-      if (ok0 || ok1)
+      if (!done && !need_bt && !atleaf)
       {
-        const uint32_t near = (ok1 && (!ok0 || lb1 < lb0)) ? 1u : 0u;
-        if (ok0 && ok1)
-          trail |= 1u << (31 - __clz(n));
-        n = 2u * n + near;
+        const float4* p = reinterpret_cast<const float4*>(a.nodes + (int64_t)n * NODE_FLOATS);
+        const float4 u = p[0], v = p[1], w = p[2];
+        const float lb0 = box_lb(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf, eabs);
+        const float lb1 = box_lb(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf, eabs);
+        const bool ok0 = lb0 <= boundf, ok1 = lb1 <= boundf;
+        if (ok0 || ok1)
+        {
+          const uint32_t near = (ok1 && (!ok0 || lb1 < lb0)) ? 1u : 0u;
+          const int lvl = 31 - __clz(n);
+          if (ok0 && ok1)
+          {
+            trail |= 1u << lvl;
+            lbleaf = (lvl == d - 1) ? (near ? lb0 : lb1) : lbleaf;
+          }
+          n = 2u * n + near;
+          atleaf = (lvl == d - 1);
+        }
+        else
+          need_bt = true;
       }
-      else
-        need_bt = true;
     }
     if (done)
       break;
@@ -284,6 +318,7 @@ __global__ __launch_bounds__(256) void k_search3(Search3Args a)
       }
     }
     need_bt = true;
+    atleaf = false;
   }
 
   if (EXACT)
@@ -328,6 +363,238 @@ __global__ __launch_bounds__(256) void k_search3(Search3Args a)
     {
       a.ovf_best[q] = best;
       a.ovf_list[base + __popcll(mo & lt)] = (uint32_t)q;
+    }
+  }
+}
+
+// The same search with lanes that outlive their queries.  A fixed grid of wavefronts
+// draws queries from a shared counter: whenever a quarter of a wavefront's lanes
+// have finished (or all of them), the finished ones write their results and take
+// the next queries off the pool.  Query costs differ widely (a point ten triangle
+// widths off the surface meets a hundred boxes, a point on it a dozen), and with
+// one query per lane for the lifetime of a wavefront most lanes sit idle waiting
+// for the slowest; refilling keeps them busy.  Results are per query and do not
+// depend on which lane ran them.  counters[2] is the pool's next query.
+constexpr int REFILL3 = 16;
+#ifndef LEAFGO3
+#define LEAFGO3 24
+#endif
+
+template <int L>
+__global__ __launch_bounds__(256) void k_search3p(Search3Args a)
+{
+  __shared__ int32_t ring[RING3][256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int d = a.tree.depth;
+
+  int64_t q = -1;
+  d3 x = mk(0.0, 0.0, 0.0);
+  float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f;
+  double tau = 0.0, best = DBL_MAX, bound = DBL_MAX;
+  float boundf = FLT_MAX;
+  int cnt = 0;
+  int32_t hs_used = -1;
+  uint32_t n = 1, trail = 0;
+  float lbleaf = 0.f;
+  bool have = false, fin = false, need_bt = false, atleaf = false;
+  bool dry = false; // the pool has run out (same for every lane of the wavefront)
+  const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
+
+  auto set_best = [&](double nb) {
+    const double r = sqrt(nb) + tau;
+    const double nbound = r * r;
+    if (nbound < best)
+      cnt = 0; // every older contender was above the old minimum
+    best = nb;
+    bound = nbound;
+    boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
+  };
+
+  while (true)
+  {
+    const bool idle = !have || fin;
+    const unsigned long long mi = __ballot(idle);
+    if (__popcll(mi) >= REFILL3 || __ballot(have && !fin) == 0ull)
+    {
+      // results of the finished queries
+      const bool f = have && fin;
+      const bool tie = f && cnt >= 2 && cnt <= RING3;
+      const bool ovf = f && cnt > RING3;
+      if (f && !tie && !ovf)
+        a.hint[q] = (cnt == 1) ? ring[0][tid] : -1;
+      const unsigned long long mt = __ballot(tie);
+      if (mt)
+      {
+        const int leader = __ffsll((long long)mt) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&a.counters[0], (uint32_t)__popcll(mt));
+        base = __shfl(base, leader, 64);
+        if (tie)
+        {
+          for (int i = 0; i < RING3; i++)
+            if (i < cnt)
+              a.cand[q * RING3 + i] = ring[i][tid];
+          a.tie_list[base + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
+        }
+      }
+      const unsigned long long mo = __ballot(ovf);
+      if (mo)
+      {
+        const int leader = __ffsll((long long)mo) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&a.counters[1], (uint32_t)__popcll(mo));
+        base = __shfl(base, leader, 64);
+        if (ovf)
+        {
+          a.ovf_best[q] = best;
+          a.ovf_list[base + __popcll(mo & lt)] = (uint32_t)q;
+        }
+      }
+      have = have && !fin;
+      fin = false;
+
+      // next queries off the pool
+      if (!dry)
+      {
+        const bool want = !have;
+        const unsigned long long mw = __ballot(want);
+        const int leader = __ffsll((long long)mw) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&a.counters[2], (uint32_t)__popcll(mw));
+        base = __shfl(base, leader, 64);
+        const int64_t nq_ = (int64_t)base + __popcll(mw & lt);
+        if (want && nq_ < total)
+        {
+          q = a.qlist ? (int64_t)a.qlist[nq_] : nq_;
+          have = true;
+          need_bt = false;
+          atleaf = false;
+          n = 1;
+          trail = 0;
+          cnt = 0;
+          hs_used = -1;
+          best = DBL_MAX;
+          bound = DBL_MAX;
+          boundf = FLT_MAX;
+          x = xform(a.T, a.qpos + 3 * q);
+          xf = (float)x.x;
+          yf = (float)x.y;
+          zf = (float)x.z;
+          const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
+          eabs = smax * 2.3841858e-07f * 1.0000002f;
+          tau = 1e-9 * (double)smax;
+          int32_t hs = a.use_hint ? a.hint[q] : -1;
+          if (hs < 0 && a.tcodes)
+          {
+            // cold start: the triangle that follows the query along the Morton curve
+            const uint64_t code = morton63(xf, yf, zf, a.box.lo, a.box.inv);
+            int64_t lo = 0, hi = a.nt;
+            while (lo < hi)
+            {
+              const int64_t mid = (lo + hi) >> 1;
+              if (a.tcodes[mid] < code)
+                lo = mid + 1;
+              else
+                hi = mid;
+            }
+            hs = (int32_t)min(lo, a.nt - 1);
+          }
+          if (hs >= 0 && a.tid[hs] >= 0)
+          {
+            d3 P0, P1, P2;
+            load_tri(a.tverts, hs, P0, P1, P2);
+            set_best(tri_d2_screen(x, P0, P1, P2));
+            ring[0][tid] = hs;
+            cnt = 1;
+            hs_used = hs;
+          }
+        }
+        dry = __ballot(want && nq_ >= total) != 0ull;
+      }
+      if (__ballot(have) == 0ull)
+        break;
+    }
+
+    // one step of the walk for every lane that is between leaves (see k_search3)
+    if (have && !fin && !atleaf)
+    {
+      if (need_bt)
+      {
+        if (trail == 0)
+          fin = true;
+        else
+        {
+          const int k = 31 - __clz(trail);
+          trail ^= 1u << k;
+          const int lvl = 31 - __clz(n);
+          n = (n >> (lvl - k - 1)) ^ 1u;
+          need_bt = false;
+          if (k == d - 1)
+          {
+            if (lbleaf > boundf)
+              need_bt = true;
+            else
+              atleaf = true;
+          }
+        }
+      }
+      if (!fin && !need_bt && !atleaf)
+      {
+        const float4* p = reinterpret_cast<const float4*>(a.nodes + (int64_t)n * NODE_FLOATS);
+        const float4 u = p[0], v = p[1], w = p[2];
+        const float lb0 = box_lb(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf, eabs);
+        const float lb1 = box_lb(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf, eabs);
+        const bool ok0 = lb0 <= boundf, ok1 = lb1 <= boundf;
+        if (ok0 || ok1)
+        {
+          const uint32_t near = (ok1 && (!ok0 || lb1 < lb0)) ? 1u : 0u;
+          const int lvl = 31 - __clz(n);
+          if (ok0 && ok1)
+          {
+            trail |= 1u << lvl;
+            lbleaf = (lvl == d - 1) ? (near ? lb0 : lb1) : lbleaf;
+          }
+          n = 2u * n + near;
+          atleaf = (lvl == d - 1);
+        }
+        else
+          need_bt = true;
+      }
+    }
+
+    // leaves are screened once enough lanes stand on one (the screen is several times the
+    // cost of a step, so it should not run for a handful of lanes), or when nobody can step
+    const bool onleaf = have && !fin && atleaf;
+    const int nleaf = __popcll(__ballot(onleaf));
+    const bool anywalk = __ballot(have && !fin && !atleaf) != 0ull;
+    if (onleaf && (nleaf >= LEAFGO3 || !anywalk))
+    {
+      const int64_t s0 = (int64_t)(n - (1u << d)) * L;
+#pragma unroll
+      for (int t = 0; t < L; t++)
+      {
+        const int64_t s = s0 + t;
+        if (s < a.nt && a.tid[s] >= 0)
+        {
+          d3 P0, P1, P2;
+          load_tri(a.tverts, s, P0, P1, P2);
+          const double d2 = tri_d2_screen(x, P0, P1, P2);
+          if (d2 < best)
+            set_best(d2);
+          if (d2 <= bound && (int32_t)s != hs_used)
+          {
+            if (cnt < RING3)
+              ring[cnt][tid] = (int32_t)s;
+            cnt++;
+          }
+        }
+      }
+      need_bt = true;
+      atleaf = false;
     }
   }
 }

@@ -25,7 +25,7 @@ SYMBOLS = (
     "icpx_accumulate", "icpx_correspond", "icpx_solve", "icpx_default_params",
     "icpx_set_allreduce", "icpx_run", "icpx_last_build_seconds", "icpx_set_group_width",
     "icpx_reset_hints", "icpx_set_timing", "icpx_get_timing", "icpx_set_exhaustive",
-    "icpx_set_leaf_size",
+    "icpx_set_leaf_size", "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local",
 )
 
 
@@ -82,6 +82,9 @@ def load():
     lib.icpx_reset_hints.argtypes = [vp]
     lib.icpx_set_exhaustive.argtypes = [vp, ci]
     lib.icpx_set_leaf_size.argtypes = [vp, ci]
+    lib.icpx_set_persistent.argtypes = [vp, ci]
+    lib.icpx_set_local.argtypes = [vp, ci]
+    lib.icpx_debug_dump.argtypes = [vp, ci, vp, i64]
     lib.icpx_set_timing.argtypes = [vp, ci]
     lib.icpx_get_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl),
                                     C.POINTER(i64)]
@@ -152,6 +155,19 @@ class Context:
 
     def synchronize(self):
         _chk(load().icpx_synchronize(self._h))
+
+    def set_local(self, enable=True):
+        _chk(load().icpx_set_local(self._h, int(bool(enable))))
+
+    def debug_stats(self):
+        """{shortcut passes, tree-only passes, neighbour-list builds, list radius}."""
+        v = np.zeros(5, np.int64)
+        _chk(load().icpx_debug_dump(self._h, 4, _p(v), 5))
+        return dict(local_passes=int(v[0]), tree_passes=int(v[1]), nbr_builds=int(v[2]),
+                    nbr_eps=float(v[3]) * 1e-9, nbr_total=int(v[4]))
+
+    def set_persistent(self, enable=True):
+        _chk(load().icpx_set_persistent(self._h, int(bool(enable))))
 
     def set_leaf_size(self, triangles):
         _chk(load().icpx_set_leaf_size(self._h, int(triangles)))

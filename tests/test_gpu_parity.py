@@ -399,6 +399,50 @@ def test_random_tiny_meshes_with_duplicates(icpx, oracle):
             ctx.close()
 
 
+def test_hinted_shortcut_matches_tree_walk(icpx, synth, oracle):
+    """Lane-per-query path over a few ICP-like passes: with the neighbour-list shortcut and
+    pooled lanes on, the sums are bit-identical to the plain tree walk's, and the rows match
+    the oracle.  Residuals from large to tiny exercise list rebuilds and the fallback."""
+    xyz, tri = synth.bumpy_torus(300, 200)
+    pts, f, fn = synth.sample_surface(xyz, tri, 60_000, seed=21)
+    noise = np.stack([synth.gaussian(21, 70 + 2 * k, len(pts)) for k in range(3)], -1) * 2e-4
+    far = synth.u01(21, 90, len(pts)) < 0.005                    # a few far outliers
+    noise[far] *= 100.0
+    T0 = synth.rigid(ry=3.0, t=(0.02, -0.01, 0.015))
+    src = synth.apply(T0, pts.astype(np.float64) + noise)
+    Tinv = np.linalg.inv(T0)
+    seq = [np.eye(4), np.eye(4), 0.5 * (np.eye(4) + Tinv), Tinv, Tinv,
+           Tinv @ synth.rigid(rz=0.01), Tinv]
+    ctxs = []
+    for local, persistent in ((True, True), (False, False), (False, True)):
+        c = icpx.Context(0)
+        c.set_group_width(1)
+        c.set_local(local)
+        c.set_persistent(persistent)
+        c.set_target(xyz, tri)
+        c.set_source(src)
+        ctxs.append(c)
+    for T in seq:
+        sums = [c.accumulate(1, T, step=1, max_dist=0.05) for c in ctxs]
+        assert np.array_equal(sums[0], sums[1]) and np.array_equal(sums[1], sums[2])
+    st = ctxs[0].debug_stats()
+    assert st["local_passes"] >= 3 and st["nbr_builds"] >= 1, st
+    assert ctxs[1].debug_stats()["local_passes"] == 0
+    mesh = oracle.Mesh(xyz, tri)
+    ref = mesh.correspond(src, T=Tinv, step=1, max_dist=0.05, grid=True)
+    for c in ctxs:
+        check_rows(c.correspond(Tinv, step=1, max_dist=0.05), ref)
+    # clean samples exactly on the surface: residual ~1e-8, the smallest list radius
+    src2 = synth.apply(T0, pts)
+    c = ctxs[0]
+    c.set_source(src2)
+    for T in (np.eye(4), Tinv, Tinv, Tinv):
+        c.accumulate(1, T, step=1, max_dist=0.05)
+    check_rows(c.correspond(Tinv, step=1, max_dist=0.05),
+               mesh.correspond(src2, T=Tinv, step=1, max_dist=0.05, grid=True))
+    assert c.debug_stats()["local_passes"] > st["local_passes"]
+
+
 def test_abi_rejects_bad_input(icpx):
     ctx = icpx.Context(0)
     v = np.zeros((3, 3), np.float32)

@@ -1,0 +1,34 @@
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from iterativeclosestpoint_amd import icpx, synth
+from oracle import oracle
+
+xyz, tri = synth.bumpy_torus(300, 200)
+pts, f, fn = synth.sample_surface(xyz, tri, 60_000, seed=21)
+noise = np.stack([synth.gaussian(21, 70 + 2 * k, len(pts)) for k in range(3)], -1) * 2e-4
+far = synth.u01(21, 90, len(pts)) < 0.005
+noise[far] *= 100.0
+T0 = synth.rigid(ry=3.0, t=(0.02, -0.01, 0.015))
+src = synth.apply(T0, pts.astype(np.float64) + noise)
+Tinv = np.linalg.inv(T0)
+seq = [np.eye(4), np.eye(4), 0.5 * (np.eye(4) + Tinv), Tinv, Tinv, Tinv @ synth.rigid(rz=0.01), Tinv]
+ctxs = []
+for local, persistent in ((True, True), (False, False), (False, True)):
+    c = icpx.Context(0)
+    c.set_group_width(1); c.set_local(local); c.set_persistent(persistent)
+    c.set_target(xyz, tri); c.set_source(src)
+    ctxs.append(c)
+mesh = oracle.Mesh(xyz, tri)
+for i, T in enumerate(seq):
+    sums = [c.accumulate(1, T, step=1, max_dist=0.05) for c in ctxs]
+    print(i, [np.array_equal(sums[0], s) for s in sums], ctxs[0].debug_stats())
+    rows = [c.correspond(T, step=1, max_dist=0.05) for c in ctxs]
+    ref = mesh.correspond(src, T=T, step=1, max_dist=0.05, grid=True)
+    for k, r in enumerate(rows):
+        if len(r["cell"]) != len(ref["cell"]):
+            print("  ctx", k, "row count", len(r["cell"]), len(ref["cell"])); continue
+        bad = np.nonzero(r["cell"] != ref["cell"])[0]
+        print("  ctx", k, "cell mismatches vs oracle:", len(bad))
+        for b in bad[:5]:
+            print("    row", b, "src", r["src_index"][b], "cell", r["cell"][b], ref["cell"][b], "dist", r["dist"][b], ref["dist"][b])

@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--widths", default="1,4,8")
     ap.add_argument("--leaf", type=int, default=2)
+    ap.add_argument("--persistent", type=int, default=1)
+    ap.add_argument("--local", type=int, default=1)
     ap.add_argument("--exhaustive", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
@@ -26,6 +28,8 @@ def main():
         ctx.set_group_width(w)
         ctx.set_exhaustive(a.exhaustive)
         ctx.set_leaf_size(a.leaf)
+        ctx.set_persistent(a.persistent)
+        ctx.set_local(a.local)
         ctx.set_target(c["target_xyz"], c["target_tri"])
         ctx.set_source(c["source_xyz"], c["source_normals"])
         ctx.accumulate(metric, np.eye(4), 1, c["max_dist"])  # builds tree, sorts queries
@@ -45,6 +49,7 @@ def main():
         ctx.accumulate(metric, Tinv, 1, c["max_dist"])
         hot1 = timed(Tinv, False)
         cold1 = timed(Tinv, True)
+        print(ctx.debug_stats())
         print("width %2d  cold@start %.3f  hinted@start %.3f  hinted@registered %.3f  "
               "cold@registered %.3f ms (min)  build %.1f ms" %
               (w, cold[0], hot0[0], hot1[0], cold1[0], 1e3 * ctx.build_seconds), flush=True)
