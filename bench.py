@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--width", type=int, default=0, help="lanes per query (0 = library default)")
+    ap.add_argument("--leaf", type=int, default=0, help="triangles per leaf (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -96,6 +97,8 @@ def main():
     sh = ShardedICP(device=local, rank=0, world=1)  # the local scan is this rank's whole shard
     if args.width:
         sh.ctx.set_group_width(args.width)
+    if args.leaf:
+        sh.ctx.set_leaf_size(args.leaf)
     sh.set_target(c["target_xyz"], c["target_tri"])
     sh.set_source(c["source_xyz"], c["source_normals"])
     origin = sh.ctx.origin

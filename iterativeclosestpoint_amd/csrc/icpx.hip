@@ -85,15 +85,15 @@ struct icpx_ctx
   Tree trees[5];  // exhaustive-exact kernel's level-array trees
   Heap heaps[5];  // group kernel's heap-ordered trees
   Bin bins[3];    // lane-per-query kernel's binary trees (1, 2, 4 triangles per leaf)
-  int leaf_size = 2;
+  int leaf_size = 4;
   int persistent = 1;
   int num_cus = 256;
   // hinted shortcut: per-leaf neighbour lists for one radius, and the residual statistics
   // of the previous pass that choose the radius
   int use_local = 1;
-  int nbr_L = 0;
-  float nbr_eps = 0.f;
-  float nbr_disabled_eps = INFINITY; // lists at this radius or above were too long
+  int nbr_state = 0;    // 0 not tried, 1 built, -1 not worth it for this mesh
+  float nbr_eps = 0.f;  // radius the lists cover
+  float mesh_edge = 0.f; // typical edge length of the target (sampled)
   uint32_t* d_noff = nullptr;
   int32_t* d_nbr = nullptr;
   uint32_t* d_fallback = nullptr;
@@ -295,8 +295,7 @@ static void free_target(icpx_ctx* c)
   dev_free(&c->d_noff);
   dev_free(&c->d_nbr);
   c->nbr_eps = 0.f;
-  c->nbr_L = 0;
-  c->nbr_disabled_eps = INFINITY;
+  c->nbr_state = 0;
   c->stat_valid = false;
   c->nv = c->nt = 0;
 }
@@ -507,7 +506,7 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
   else if (what == 2 && c->d_counters)
   {
     src = c->d_counters;
-    bytes = sizeof(uint32_t) * 2;
+    bytes = sizeof(uint32_t) * (size_t)std::min<int64_t>(count, 4);
   }
   else if (what == 4)
   {
@@ -652,6 +651,21 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   c->scene_max = 0.f;
   for (int a = 0; a < 3; a++)
     c->scene_max = std::fmax(c->scene_max, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+  {
+    // typical edge length, from an even sample of the triangles (sizes the neighbour lists)
+    const int64_t stride = std::max<int64_t>(1, nt / 8192);
+    double sum = 0.0;
+    int64_t cnt = 0;
+    for (int64_t t = 0; t < nt; t += stride, cnt++)
+      for (int k = 0; k < 3; k++)
+      {
+        const float* p = xyz + 3 * (int64_t)tri[3 * t + k];
+        const float* q = xyz + 3 * (int64_t)tri[3 * t + (k + 1) % 3];
+        const double dx = (double)p[0] - q[0], dy = (double)p[1] - q[1], dz = (double)p[2] - q[2];
+        sum += std::sqrt(dx * dx + dy * dy + dz * dz);
+      }
+    c->mesh_edge = (float)(sum / (3.0 * (double)cnt));
+  }
 
   ALLOC(c->d_xyz, 3 * nv);
   ALLOC(c->d_tri, 3 * nt);
@@ -979,9 +993,9 @@ static void launch_search3(const Search3Args& a, unsigned grid, unsigned pgrid, 
   k_search3<L, true><<<grid, 256, 0, st>>>(a);
 }
 
-// Neighbour lists of every leaf for radius eps (see local.hpp).  Returns ICPX_OK with
-// c->nbr_eps == 0 when the lists would be too long to pay off.
-static int build_nbr(icpx_ctx* c, const Bin& b, int L, float eps)
+// Neighbour lists of every leaf of the one-triangle-per-leaf tree for radius eps (see
+// local.hpp).  Leaves c->nbr_eps == 0 when the lists would be too long to pay off.
+static int build_nbr(icpx_ctx* c, const Bin& b, float eps)
 {
   hipStream_t st = c->stream;
   dev_free(&c->d_noff);
@@ -1006,26 +1020,26 @@ static int build_nbr(icpx_ctx* c, const Bin& b, int L, float eps)
     return fail(ICPX_E_HIP, "neighbour count failed: %s", hipGetErrorString(e));
   c->nbr_builds++;
   c->nbr_total = total;
-  if ((double)total > 48.0 * (double)nl)
+  if ((double)total > 32.0 * (double)nl)
   {
-    c->nbr_disabled_eps = eps; // too many neighbours at this radius: the tree walk is better
-    dev_free(&c->d_noff);
+    dev_free(&c->d_noff); // too many neighbours at this radius: the tree walk is better
     return ICPX_OK;
   }
-  ALLOC(c->d_nbr, (int64_t)total + 1);
+  ALLOC(c->d_nbr, (int64_t)total + 4);
   k_nbr<true><<<nblk(nl, 256), 256, 0, st>>>(b.nodes, b.t, eps2, nullptr, c->d_noff, c->d_nbr);
   LAUNCHCHK();
   c->nbr_eps = eps;
-  c->nbr_L = L;
   return ICPX_OK;
 }
 
-// Radius policy: lists should cover queries up to four times the previous pass's mean
-// residual (2r <= eps), and are rebuilt when the residual leaves the band they suit.
-static int prepare_local(icpx_ctx* c, const Bin& b, int L, bool* use)
+// The shortcut serves a pass once the previous pass's mean residual is a fraction of the
+// radius the lists cover.  The radius is a quarter of the target's typical edge length
+// (halved up to three times if that makes the lists long); the lists are built the first
+// time they would be used and stay until the target changes.
+static int prepare_local(icpx_ctx* c, bool* use)
 {
   *use = false;
-  if (!c->use_local || !c->hint_valid)
+  if (!c->use_local || !c->hint_valid || c->nbr_state < 0)
     return ICPX_OK;
   if (c->stat_pending)
   {
@@ -1037,21 +1051,28 @@ static int prepare_local(icpx_ctx* c, const Bin& b, int L, bool* use)
   }
   if (!c->stat_valid)
     return ICPX_OK;
-  const double floor_eps = 256.0 * 2.3841858e-07 * (double)c->scene_max;
   const double mean = c->last_mean;
-  const bool fits = c->nbr_eps > 0.f && c->nbr_L == L &&
-    (double)c->nbr_eps >= std::fmax(4.0 * mean, floor_eps * 0.999) &&
-    (double)c->nbr_eps <= std::fmax(64.0 * mean, floor_eps * 1.001);
-  if (!fits)
+  if (c->nbr_state == 0)
   {
-    const float eps = (float)std::fmax(8.0 * mean, floor_eps);
-    if (eps >= 0.5f * c->nbr_disabled_eps)
-      return ICPX_OK;
-    int rc = build_nbr(c, b, L, eps);
+    const double floor_eps = 256.0 * 2.3841858e-07 * (double)c->scene_max;
+    double eps = std::fmax(0.25 * (double)c->mesh_edge, floor_eps);
+    if (3.0 * mean > eps)
+      return ICPX_OK; // not close enough yet
+    int rc = ensure_bin(c, 1);
     if (rc)
       return rc;
+    for (int attempt = 0; attempt < 4; attempt++)
+    {
+      rc = build_nbr(c, c->bins[0], (float)eps);
+      if (rc)
+        return rc;
+      if (c->nbr_eps > 0.f || eps <= floor_eps)
+        break;
+      eps = std::fmax(0.5 * eps, floor_eps);
+    }
+    c->nbr_state = c->nbr_eps > 0.f ? 1 : -1;
   }
-  *use = c->nbr_eps > 0.f;
+  *use = c->nbr_state == 1 && 3.0 * mean <= (double)c->nbr_eps;
   return ICPX_OK;
 }
 
@@ -1095,7 +1116,7 @@ static int run_search3(icpx_ctx* c, const double T[16])
   hipStream_t st = c->stream;
   const unsigned grid = nblk(c->nq, 256);
   bool use_local = false;
-  rc = prepare_local(c, b, L, &use_local);
+  rc = prepare_local(c, &use_local);
   if (rc)
     return rc;
   ScopedTimer tm(c, 0);
@@ -1104,16 +1125,13 @@ static int run_search3(icpx_ctx* c, const double T[16])
   {
     LocalArgs la;
     la.s = a;
+    la.s.nodes = c->bins[0].nodes; // the lists index the one-triangle-per-leaf tree
+    la.s.tree = c->bins[0].t;
     la.noff = c->d_noff;
     la.nbr = c->d_nbr;
     la.eps = c->nbr_eps;
     la.fallback = c->d_fallback;
-    if (L == 1)
-      k_search_local<1><<<grid, 256, 0, st>>>(la);
-    else if (L == 2)
-      k_search_local<2><<<grid, 256, 0, st>>>(la);
-    else
-      k_search_local<4><<<grid, 256, 0, st>>>(la);
+    k_search_local<1><<<grid, 256, 0, st>>>(la);
     a.qlist = c->d_fallback; // the tree kernel serves what is left
     c->local_passes++;
   }

@@ -11,8 +11,9 @@
 // are appended to a list that the tree kernel then serves.  The contenders found
 // are the same as the tree walk's, so the winner is too.
 //
-// eps follows the registration: the host asks for four times the mean residual of
-// the previous pass and rebuilds the lists when that leaves the band they cover.
+// eps is a property of the mesh (a fraction of its typical edge length, chosen by the
+// host so that the lists stay short); the lists are built once per target, the first
+// time the mean residual of a pass has come down to a fraction of eps.
 #pragma once
 #include "search3.hpp"
 
@@ -186,44 +187,60 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
     }
   }
 
-  int32_t cur = -1;
-  while (true)
+  // The list is taken four entries at a time: four indices, then four boxes, are in
+  // flight together (the loads of one entry depend on each other, those of different
+  // entries do not), and only the entries whose boxes pass are screened.
+  while (local && e < eend)
   {
-    // next neighbouring leaf whose box is within the bound
-    while (local && cur < 0 && e < eend)
+    int32_t m[4];
+    float lb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      m[k] = la.nbr[min(e + k, eend - 1)];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
     {
-      const int32_t m = la.nbr[e++];
-      const uint32_t heap = (1u << d) + (uint32_t)m;
+      const uint32_t heap = (1u << d) + (uint32_t)m[k];
       const float* r = a.nodes + (int64_t)(heap >> 1) * NODE_FLOATS + 6 * (heap & 1u);
       const float2 b0 = *reinterpret_cast<const float2*>(r);
       const float2 b1 = *reinterpret_cast<const float2*>(r + 2);
       const float2 b2 = *reinterpret_cast<const float2*>(r + 4);
-      if (box_lb(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, xf, yf, zf, eabs) <= boundf)
-        cur = m;
+      lb[k] = box_lb(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, xf, yf, zf, eabs);
     }
-    if (cur < 0)
-      break;
-    const int64_t s0 = (int64_t)cur * L;
+    uint32_t pass = 0;
 #pragma unroll
-    for (int t = 0; t < L; t++)
+    for (int k = 0; k < 4; k++)
+      pass |= (e + k < eend && lb[k] <= boundf) ? (1u << k) : 0u;
+    e += 4;
+    while (pass)
     {
-      const int64_t s = s0 + t;
-      if (s < a.nt && a.tid[s] >= 0 && (int32_t)s != hs)
+      const int k = __ffs((int)pass) - 1;
+      pass &= pass - 1;
+      const int32_t cur = (k == 0) ? m[0] : (k == 1) ? m[1] : (k == 2) ? m[2] : m[3];
+      const float lbk = (k == 0) ? lb[0] : (k == 1) ? lb[1] : (k == 2) ? lb[2] : lb[3];
+      if (lbk > boundf)
+        continue; // the bound tightened since the test
+      const int64_t s0 = (int64_t)cur * L;
+#pragma unroll
+      for (int t = 0; t < L; t++)
       {
-        d3 P0, P1, P2;
-        load_tri(a.tverts, s, P0, P1, P2);
-        const double d2 = tri_d2_screen(x, P0, P1, P2);
-        if (d2 < best)
-          set_best(d2);
-        if (d2 <= bound)
+        const int64_t s = s0 + t;
+        if (s < a.nt && a.tid[s] >= 0 && (int32_t)s != hs)
         {
-          if (cnt < RING3)
-            ring[cnt][tid] = (int32_t)s;
-          cnt++;
+          d3 P0, P1, P2;
+          load_tri(a.tverts, s, P0, P1, P2);
+          const double d2 = tri_d2_screen(x, P0, P1, P2);
+          if (d2 < best)
+            set_best(d2);
+          if (d2 <= bound)
+          {
+            if (cnt < RING3)
+              ring[cnt][tid] = (int32_t)s;
+            cnt++;
+          }
         }
       }
     }
-    cur = -1;
   }
 
   // settle (as the tree kernel does)

@@ -400,6 +400,8 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
   bool have = false, fin = false, need_bt = false, atleaf = false;
   bool dry = false; // the pool has run out (same for every lane of the wavefront)
   const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
+  if ((int64_t)blockIdx.x * 256 >= total)
+    return; // a short list is served by the first blocks; the rest must not queue at the pool
 
   auto set_best = [&](double nb) {
     const double r = sqrt(nb) + tau;

@@ -166,6 +166,12 @@ class Context:
         return dict(local_passes=int(v[0]), tree_passes=int(v[1]), nbr_builds=int(v[2]),
                     nbr_eps=float(v[3]) * 1e-9, nbr_total=int(v[4]))
 
+    def debug_counters(self):
+        """Counters of the last lane-per-query pass: {ties, overflows, pool position, fallbacks}."""
+        v = np.zeros(4, np.uint32)
+        _chk(load().icpx_debug_dump(self._h, 2, _p(v), 4))
+        return dict(ties=int(v[0]), overflows=int(v[1]), pool=int(v[2]), fallback=int(v[3]))
+
     def set_persistent(self, enable=True):
         _chk(load().icpx_set_persistent(self._h, int(bool(enable))))
 

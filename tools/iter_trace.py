@@ -1,0 +1,49 @@
+"""Development aid: per-iteration search / finalize kernel times and wall time of a
+cold-start registration on a workload."""
+import argparse
+import os
+import sys
+import time
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from iterativeclosestpoint_amd import icpx, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--leaf", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=30)
+    a = ap.parse_args()
+    c = {"c3": synth.config_c3, "c4": synth.config_c4}[a.workload]()
+    metric = c["metric"]
+    ctx = icpx.Context(0)
+    if a.width:
+        ctx.set_group_width(a.width)
+    if a.leaf:
+        ctx.set_leaf_size(a.leaf)
+    ctx.set_target(c["target_xyz"], c["target_tri"])
+    ctx.set_source(c["source_xyz"], c["source_normals"])
+    for rep in range(2):
+        ctx.reset_hints()
+        T = np.eye(4)
+        ctx.set_timing(True)
+        ps = pf = 0.0
+        for it in range(a.iters):
+            t0 = time.perf_counter()
+            sums = ctx.accumulate(metric, T, 1, c["max_dist"])
+            M, n, md, rc = icpx.solve(metric, sums, ctx.origin)
+            T = M @ T
+            wall = 1e3 * (time.perf_counter() - t0)
+            s_ms, s_n, f_ms, f_n = ctx.get_timing()
+            if rep == 1:
+                print("it %2d  wall %.3f  search %.3f  finalize %.3f  n %d  mean %.3e  %s" %
+                      (it, wall, s_ms - ps, f_ms - pf, n, md, ctx.debug_counters()), flush=True)
+            ps, pf = s_ms, f_ms
+        ctx.set_timing(False)
+
+
+if __name__ == "__main__":
+    main()
