@@ -164,6 +164,32 @@ extern "C"
   int icpx_run(icpx_ctx* ctx, const icpx_params* p, double T_out[16], int* iterations_out,
     double* mean_distance_out, int* status_out);
 
+  /* The same loop, one iteration at a time and without a host round trip, for a driver
+   * that reduces the sums over GPUs with a stream-ordered collective (RCCL through
+   * torch.distributed, or ncclAllReduce on the context's stream).  The transform, the
+   * iteration count and the stop condition live on the device: icpx_run_update solves
+   * there (one GPU thread running the code of icpx_solve) and, once the run has converged
+   * or run out of rows, every pass enqueued afterwards returns at once, so T_out,
+   * iterations and status are exactly those of icpx_run.  Nothing blocks except that the
+   * host stays at most two iterations ahead of the device.
+   *
+   *   icpx_run_begin(ctx, p);
+   *   for (i = 0; i < p->max_iterations; i++) {
+   *     icpx_run_enqueue(ctx, sums_dev, &done);   // search + fused sums -> sums_dev
+   *     if (done) break;                          // (known two iterations late; harmless)
+   *     all-reduce sums_dev in place on the same stream;
+   *     icpx_run_update(ctx, sums_dev);           // solve, T <- M*T, stop test
+   *   }
+   *   icpx_run_end(ctx, T, &iters, &mean, &status);   // waits for the stream
+   *
+   * sums_device = NULL uses an internal buffer (single GPU; icpx_run does exactly that).
+   * Replaces ICP/vtkICP.cxx:189-246 like icpx_run; the reference has no multi-GPU loop. */
+  int icpx_run_begin(icpx_ctx* ctx, const icpx_params* p);
+  int icpx_run_enqueue(icpx_ctx* ctx, double* sums_device, int* done_out);
+  int icpx_run_update(icpx_ctx* ctx, const double* sums_device);
+  int icpx_run_end(icpx_ctx* ctx, double T_out[16], int* iterations_out,
+    double* mean_distance_out, int* status_out);
+
   /* Wall-clock seconds the last icpx_set_target spent building the BVH and
    * tables on the device (for reporting; not part of the reference surface). */
   double icpx_last_build_seconds(icpx_ctx* ctx);
@@ -175,13 +201,13 @@ extern "C"
    * Trees are built on first use.  Results do not depend on the choice. */
   int icpx_set_group_width(icpx_ctx* ctx, int lanes);
 
-  /* Triangles per leaf of the lane-per-query kernel's tree: 1, 2 (default) or 4. */
+  /* Triangles per leaf of the lane-per-query kernel's tree: 1, 2 or 4 (default). */
   int icpx_set_leaf_size(icpx_ctx* ctx, int triangles);
 
-  /* Hinted shortcut of the lane-per-query path: 1 (default) = when the previous pass left
-   * a small residual, queries close to their previous winner test only the leaves near
-   * that winner's leaf (precomputed neighbour lists) instead of walking the tree; the
-   * rest still walk it.  0 = always walk the tree.  Same results. */
+  /* Hinted shortcut of the lane-per-query path: 1 (default) = once the mean residual is a
+   * fraction of the target's edge length, queries close to their previous winner test only
+   * the triangles near it (per-triangle neighbour lists, built once per target) instead of
+   * walking the tree; the rest still walk it.  0 = always walk the tree.  Same results. */
   int icpx_set_local(icpx_ctx* ctx, int enable);
 
   /* Lane-per-query kernel scheduling: 1 (default) = a resident grid whose lanes draw
@@ -200,7 +226,8 @@ extern "C"
   /* Diagnostic: copy an internal array to the host.  what = 0: winners of the last search
    * pass (Morton positions of triangles, int32 per query of this shard); 1: Morton
    * position -> cell id (int32 per triangle, -1-id for a degenerate one); 2: {ties,
-   * overflows} counted by the last lane-per-query pass (2 x uint32); 4: {shortcut passes,
+   * overflows, pool position, shortcut fallbacks} of the last lane-per-query pass (4 x
+   * uint32); 4: {shortcut passes,
    * tree-only passes, neighbour-list builds, list radius x 1e9, list entries} (5 x int64). */
   int icpx_debug_dump(icpx_ctx* ctx, int what, void* out, int64_t count);
 

@@ -10,6 +10,7 @@
 #include "search2.hpp"
 #include "search3.hpp"
 #include "local.hpp"
+#include "solve_core.hpp"
 #include "tables.hpp"
 
 #include <chrono>
@@ -67,6 +68,118 @@ struct Bin
   bool built = false;
 };
 
+// State of a registration that stays on the device between iterations.
+struct RunState
+{
+  double T[16]; // running transform, row-major
+  // ---- the 32 bytes from here on are what the host polls (RunRecord)
+  double mean, n;  // of the last solved iteration
+  int32_t iters;   // solved iterations (vtkICP's NumberOfIterations)
+  int32_t status;  // ICPX_RUN_*
+  int32_t done;    // 1: converged / too few rows; later passes return at once
+  uint32_t fallback; // queries the shortcut left to the tree walk in the last pass
+};
+struct RunRecord
+{
+  double mean, n;
+  int32_t iters, status, done;
+  uint32_t fallback;
+};
+struct Mat16
+{
+  double m[16];
+};
+
+__global__ void k_set_state(RunState* s, Mat16 T, int reset)
+{
+  const int i = threadIdx.x;
+  if (i < 16)
+    s->T[i] = T.m[i];
+  if (i == 0)
+  {
+    s->done = 0;
+    if (reset)
+    {
+      s->mean = 0.0;
+      s->n = 0.0;
+      s->iters = 0;
+      s->status = ICPX_RUN_MAX_ITERATIONS;
+      s->fallback = 0;
+    }
+  }
+}
+
+// One iteration's solve and transform update in a single GPU thread: the body of the
+// loop in vtkICP::InternalUpdate after the correspondence filter (ICP/vtkICP.cxx:218-245).
+// The iteration's record goes straight to pinned host memory (rec), where the host reads
+// it behind an event two iterations later.
+__device__ void solve_step(RunState* s, const double* __restrict__ sums, int metric,
+  const double* origin, int check_mean, double max_mean)
+{
+  double M[16], n = 0.0, md = 0.0;
+  const int rc = icpx_core::solve_moments(metric, sums, origin, M, &n, &md);
+  s->mean = md;
+  s->n = n;
+  if (check_mean && n > 0.0 && md <= max_mean)
+  {
+    s->status = ICPX_RUN_CONVERGED;
+    s->done = 1;
+    return;
+  }
+  if (rc != ICPX_OK)
+  {
+    s->status = ICPX_RUN_TOO_FEW;
+    s->done = 1;
+    return;
+  }
+  s->iters = s->iters + 1;
+  double R[16];
+  for (int r = 0; r < 4; r++)
+    for (int k = 0; k < 4; k++)
+    {
+      double acc = 0.0;
+      for (int j = 0; j < 4; j++)
+        acc += M[4 * r + j] * s->T[4 * j + k];
+      R[4 * r + k] = acc;
+    }
+  for (int i = 0; i < 16; i++)
+    s->T[i] = R[i];
+}
+
+// {n, sum |s-t|, shortcut fallbacks} of a pass, written to pinned host memory.
+__global__ void k_pass_stat(const double* __restrict__ sums, const uint32_t* __restrict__ counters,
+  double* stat)
+{
+  if (threadIdx.x == 0)
+  {
+    stat[0] = sums[0];
+    stat[1] = sums[1];
+    stat[2] = counters ? (double)counters[7] : 0.0;
+    __threadfence_system();
+  }
+}
+
+__global__ void k_solve(RunState* s, const double* __restrict__ sums, int metric, double ox,
+  double oy, double oz, int check_mean, double max_mean, const uint32_t* __restrict__ counters,
+  RunRecord* rec)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0)
+    return;
+  if (!s->done)
+  {
+    const double origin[3] = { ox, oy, oz };
+    s->fallback = counters ? counters[7] : 0u; // snapshot of the pass's fallback count
+    solve_step(s, sums, metric, origin, check_mean, max_mean);
+  }
+  rec->mean = s->mean;
+  rec->n = s->n;
+  rec->iters = s->iters;
+  rec->status = s->status;
+  rec->done = s->done;
+  rec->fallback = s->fallback;
+  __threadfence_system();
+}
+
 struct icpx_ctx
 {
   int device = 0;
@@ -97,10 +210,22 @@ struct icpx_ctx
   uint32_t* d_noff = nullptr;
   int32_t* d_nbr = nullptr;
   uint32_t* d_fallback = nullptr;
-  double* h_stat = nullptr; // pinned {n, sum |s-t|} of the last accumulate pass
+  double* h_stat = nullptr; // pinned {n, sum |s-t|, shortcut fallbacks} of a finished pass
   hipEvent_t ev_stat = nullptr;
   bool stat_pending = false, stat_valid = false;
   double last_mean = 0.0;
+  int local_holdoff = 0; // passes to go without the shortcut (it served too few queries)
+  int bad_streak = 0;    // consecutive passes it served too few queries while the residual was large
+  // device-resident loop
+  RunState* d_state = nullptr;
+  RunRecord* h_rec = nullptr; // pinned ring of the last four iterations' records
+  RunRecord* d_rec = nullptr; // the same memory as the device sees it
+  double* d_stat = nullptr;   // h_stat as the device sees it
+  bool counters_clean = false; // the pass counters are zero (the reduction left them so)
+  hipEvent_t ev_rec[4] = { nullptr, nullptr, nullptr, nullptr };
+  bool run_active = false, run_done_known = false;
+  int64_t run_it = 0, run_step = 1;
+  icpx_params run_p;
   int64_t local_passes = 0, tree_passes = 0, nbr_builds = 0, nbr_total = 0;
   // lane-per-query kernel's tie bookkeeping, sized for q3_cap queries
   int64_t q3_cap = 0;
@@ -379,10 +504,23 @@ extern "C" int icpx_create(icpx_ctx** out, int device)
     rc = dev_alloc(&c->d_sums, ICPX_NSUMS);
   if (!rc && hipHostMalloc((void**)&c->h_sums, sizeof(double) * ICPX_NSUMS) != hipSuccess)
     rc = fail(ICPX_E_NOMEM, "hipHostMalloc failed");
-  if (!rc && hipHostMalloc((void**)&c->h_stat, sizeof(double) * 2) != hipSuccess)
+  if (!rc &&
+    (hipHostMalloc((void**)&c->h_stat, sizeof(double) * 4,
+       hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->d_stat, c->h_stat, 0) != hipSuccess))
     rc = fail(ICPX_E_NOMEM, "hipHostMalloc failed");
   if (!rc && hipEventCreateWithFlags(&c->ev_stat, hipEventDisableTiming) != hipSuccess)
     rc = fail(ICPX_E_HIP, "hipEventCreate failed");
+  if (!rc)
+    rc = dev_alloc(&c->d_state, 1);
+  if (!rc &&
+    (hipHostMalloc((void**)&c->h_rec, sizeof(RunRecord) * 4,
+       hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->d_rec, c->h_rec, 0) != hipSuccess))
+    rc = fail(ICPX_E_NOMEM, "hipHostMalloc failed");
+  for (int i = 0; i < 4 && !rc; i++)
+    if (hipEventCreateWithFlags(&c->ev_rec[i], hipEventDisableTiming) != hipSuccess)
+      rc = fail(ICPX_E_HIP, "hipEventCreate failed");
   if (rc)
   {
     icpx_destroy(c);
@@ -412,6 +550,12 @@ extern "C" void icpx_destroy(icpx_ctx* c)
     (void)hipHostFree(c->h_stat);
   if (c->ev_stat)
     (void)hipEventDestroy(c->ev_stat);
+  dev_free(&c->d_state);
+  if (c->h_rec)
+    (void)hipHostFree(c->h_rec);
+  for (auto e : c->ev_rec)
+    if (e)
+      (void)hipEventDestroy(e);
   resolve_timing(c);
   for (auto e : c->free_events)
     (void)hipEventDestroy(e);
@@ -505,7 +649,7 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
   }
   else if (what == 2 && c->d_counters)
   {
-    src = c->d_counters;
+    src = c->d_counters + (c->counters_clean ? 4 : 0); // the reduction moves them up
     bytes = sizeof(uint32_t) * (size_t)std::min<int64_t>(count, 4);
   }
   else if (what == 4)
@@ -541,6 +685,8 @@ extern "C" int icpx_set_local(icpx_ctx* c, int enable)
   if (!c)
     return fail(ICPX_E_INVALID, "null context");
   c->use_local = enable ? 1 : 0;
+  c->local_holdoff = 0; // (and the policy starts afresh)
+  c->bad_streak = 0;
   return ICPX_OK;
 }
 
@@ -567,6 +713,8 @@ extern "C" int icpx_reset_hints(icpx_ctx* c)
   c->hint_valid = false;
   c->stat_valid = false;
   c->stat_pending = false;
+  c->local_holdoff = 0;
+  c->bad_streak = 0;
   return ICPX_OK;
 }
 
@@ -941,10 +1089,22 @@ static int prepare_queries(icpx_ctx* c, int64_t step)
   return ICPX_OK;
 }
 
-static void fill_xf(Xf& x, const double T[16])
+static XfRef xf_ref(icpx_ctx* c)
 {
-  for (int i = 0; i < 12; i++)
-    x.m[i] = T[i];
+  XfRef r;
+  r.T = c->d_state->T;
+  r.stop = &c->d_state->done;
+  return r;
+}
+
+// Puts a host transform into the device state the kernels read (stream-ordered).
+static int set_transform(icpx_ctx* c, const double T[16], int reset)
+{
+  Mat16 m;
+  std::memcpy(m.m, T, sizeof(m.m));
+  k_set_state<<<1, 64, 0, c->stream>>>(c->d_state, m, reset);
+  LAUNCHCHK();
+  return ICPX_OK;
 }
 
 static int pick_width(const icpx_ctx* c)
@@ -1032,51 +1192,73 @@ static int build_nbr(icpx_ctx* c, const Bin& b, float eps)
   return ICPX_OK;
 }
 
-// The shortcut serves a pass once the previous pass's mean residual is a fraction of the
-// radius the lists cover.  The radius is a quarter of the target's typical edge length
-// (halved up to three times if that makes the lists long); the lists are built the first
-// time they would be used and stay until the target changes.
-static int prepare_local(icpx_ctx* c, bool* use)
+// Neighbour lists for the shortcut, built once per target: the radius is a quarter of the
+// target's typical edge length, halved up to three times if that makes the lists long.
+static int ensure_lists(icpx_ctx* c)
 {
-  *use = false;
-  if (!c->use_local || !c->hint_valid || c->nbr_state < 0)
+  if (c->nbr_state != 0)
     return ICPX_OK;
-  if (c->stat_pending)
+  const double floor_eps = 256.0 * 2.3841858e-07 * (double)c->scene_max;
+  double eps = std::fmax(0.25 * (double)c->mesh_edge, floor_eps);
+  int rc = ensure_bin(c, 1);
+  if (rc)
+    return rc;
+  for (int attempt = 0; attempt < 4; attempt++)
   {
-    HIPCHK(hipEventSynchronize(c->ev_stat));
-    c->stat_pending = false;
-    c->stat_valid = c->h_stat[0] > 0.0;
-    if (c->stat_valid)
-      c->last_mean = c->h_stat[1] / c->h_stat[0];
-  }
-  if (!c->stat_valid)
-    return ICPX_OK;
-  const double mean = c->last_mean;
-  if (c->nbr_state == 0)
-  {
-    const double floor_eps = 256.0 * 2.3841858e-07 * (double)c->scene_max;
-    double eps = std::fmax(0.25 * (double)c->mesh_edge, floor_eps);
-    if (3.0 * mean > eps)
-      return ICPX_OK; // not close enough yet
-    int rc = ensure_bin(c, 1);
+    rc = build_nbr(c, c->bins[0], (float)eps);
     if (rc)
       return rc;
-    for (int attempt = 0; attempt < 4; attempt++)
-    {
-      rc = build_nbr(c, c->bins[0], (float)eps);
-      if (rc)
-        return rc;
-      if (c->nbr_eps > 0.f || eps <= floor_eps)
-        break;
-      eps = std::fmax(0.5 * eps, floor_eps);
-    }
-    c->nbr_state = c->nbr_eps > 0.f ? 1 : -1;
+    if (c->nbr_eps > 0.f || eps <= floor_eps)
+      break;
+    eps = std::fmax(0.5 * eps, floor_eps);
   }
-  *use = c->nbr_state == 1 && 3.0 * mean <= (double)c->nbr_eps;
+  c->nbr_state = c->nbr_eps > 0.f ? 1 : -1;
   return ICPX_OK;
 }
 
-static int run_search3(icpx_ctx* c, const double T[16])
+// A finished pass's figures, for the shortcut's policy (see prepare_local).
+static void note_pass(icpx_ctx* c, double n, double mean, double fallback)
+{
+  const bool bad = n > 0.0 && fallback > 0.5 * (double)c->nq && 3.0 * mean > (double)c->nbr_eps;
+  c->bad_streak = bad ? c->bad_streak + 1 : 0;
+  if (c->bad_streak >= 2 && c->local_holdoff == 0)
+  {
+    c->local_holdoff = 8;
+    c->bad_streak = 0;
+  }
+}
+
+// Whether this pass tries the shortcut first: always once the lists exist (a query it
+// cannot settle costs a short walk before it joins the tree walk), except for a few
+// passes after two in a row that left most queries to the tree walk while the mean
+// residual was beyond the lists' reach (noisy scans never get close enough).  Both
+// figures reach the host a pass or two late.
+static int prepare_local(icpx_ctx* c, bool* use)
+{
+  *use = false;
+  if (!c->use_local || c->nbr_state < 0)
+    return ICPX_OK;
+  if (!c->hint_valid)
+    return ICPX_OK; // a cold pass: a walk from the Morton seed settles too few queries to pay
+  if (c->stat_pending && hipEventQuery(c->ev_stat) == hipSuccess)
+  {
+    c->stat_pending = false;
+    note_pass(c, c->h_stat[0], c->h_stat[0] > 0.0 ? c->h_stat[1] / c->h_stat[0] : 0.0,
+      c->h_stat[2]);
+  }
+  if (c->local_holdoff > 0)
+  {
+    c->local_holdoff--;
+    return ICPX_OK;
+  }
+  int rc = ensure_lists(c);
+  if (rc)
+    return rc;
+  *use = c->nbr_state == 1;
+  return ICPX_OK;
+}
+
+static int run_search3(icpx_ctx* c)
 {
   const int L = c->leaf_size;
   int rc = ensure_bin(c, L);
@@ -1086,7 +1268,8 @@ static int run_search3(icpx_ctx* c, const double T[16])
   {
     ALLOC(c->d_cand, c->nq * RING3);
     ALLOC(c->d_tie_list, c->nq);
-    ALLOC(c->d_counters, 4);
+    ALLOC(c->d_counters, 8);
+    c->counters_clean = false;
     ALLOC(c->d_ovf_list, c->nq);
     ALLOC(c->d_ovf_best, c->nq);
     ALLOC(c->d_fallback, c->nq);
@@ -1096,7 +1279,7 @@ static int run_search3(icpx_ctx* c, const double T[16])
   Search3Args a;
   a.qpos = c->d_qpos;
   a.nq = c->nq;
-  fill_xf(a.T, T);
+  a.T = xf_ref(c);
   a.nodes = b.nodes;
   a.tree = b.t;
   a.tverts = c->d_tverts;
@@ -1120,7 +1303,9 @@ static int run_search3(icpx_ctx* c, const double T[16])
   if (rc)
     return rc;
   ScopedTimer tm(c, 0);
-  HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), st));
+  if (!c->counters_clean)
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), st));
+  c->counters_clean = false;
   if (use_local)
   {
     LocalArgs la;
@@ -1131,8 +1316,9 @@ static int run_search3(icpx_ctx* c, const double T[16])
     la.nbr = c->d_nbr;
     la.eps = c->nbr_eps;
     la.fallback = c->d_fallback;
-    k_search_local<1><<<grid, 256, 0, st>>>(la);
-    a.qlist = c->d_fallback; // the tree kernel serves what is left
+    k_search_local<<<grid, 256, 0, st>>>(la);
+    a.qlist = c->d_fallback; // the tree kernel serves what is left,
+    a.use_hint = 1;          // starting from the triangles the shortcut reached
     c->local_passes++;
   }
   else
@@ -1163,11 +1349,11 @@ static void launch_search2(const Search2Args& a, unsigned grid, hipStream_t st)
   k_search2<G><<<grid, 256, 0, st>>>(a);
 }
 
-static int run_search(icpx_ctx* c, const double T[16])
+static int run_search(icpx_ctx* c)
 {
   const int G = pick_width(c);
   if (G == 1)
-    return run_search3(c, T);
+    return run_search3(c);
   int slot = 0;
   for (int i = 0; i < 5; i++)
     if (kWidths[i] == G)
@@ -1183,7 +1369,7 @@ static int run_search(icpx_ctx* c, const double T[16])
     Search2Args a;
     a.qpos = c->d_qpos;
     a.nq = c->nq;
-    fill_xf(a.T, T);
+    a.T = xf_ref(c);
     a.nodes = h.nodes;
     a.tree = h.t;
     a.tverts = c->d_tverts;
@@ -1222,7 +1408,7 @@ static int run_search(icpx_ctx* c, const double T[16])
   SearchArgs a;
   a.qpos = c->d_qpos;
   a.nq = c->nq;
-  fill_xf(a.T, T);
+  a.T = xf_ref(c);
   a.nodes = t.nodes;
   a.lv = t.lv;
   a.tverts = c->d_tverts;
@@ -1254,7 +1440,7 @@ static int run_search(icpx_ctx* c, const double T[16])
   return ICPX_OK;
 }
 
-static void fill_final(icpx_ctx* c, FinalArgs& f, const double T[16], double max_dist,
+static void fill_final(icpx_ctx* c, FinalArgs& f, double max_dist,
   double min_dot, int use_sn, bool want_sn)
 {
   std::memset(&f, 0, sizeof(f));
@@ -1262,7 +1448,7 @@ static void fill_final(icpx_ctx* c, FinalArgs& f, const double T[16], double max
   f.qsn = want_sn ? c->d_qsn : nullptr;
   f.qk = c->d_qk;
   f.nq = c->nq;
-  fill_xf(f.T, T);
+  f.T = xf_ref(c);
   for (int i = 0; i < 3; i++)
     f.origin[i] = c->origin[i];
   f.tverts = c->d_tverts;
@@ -1292,6 +1478,54 @@ static int check_call(icpx_ctx* c, const double* T, int metric, int use_sn)
   return ICPX_OK;
 }
 
+// Search + fused sums of one pass, enqueued on the stream; the transform is the one in
+// the device state.  `stat` asks for the pass's {n, sum |s-t|} to be copied to the host
+// behind an event (for callers that do not run the device-resident loop).
+static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, double min_dot,
+  int use_sn, double* dst, bool stat)
+{
+  int rc = prepare_queries(c, step);
+  if (rc)
+    return rc;
+  hipStream_t st = c->stream;
+  if (c->nq == 0)
+  {
+    HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * ICPX_NSUMS, st));
+    return ICPX_OK;
+  }
+  rc = run_search(c);
+  if (rc)
+    return rc;
+  FinalArgs f;
+  fill_final(c, f, max_dist, min_dot, use_sn, use_sn || metric == ICPX_METRIC_PLANE_TO_PLANE);
+  int grid = (int)nblk(c->nq, FIN_THREADS);
+  if (grid > c->max_blocks)
+    grid = c->max_blocks;
+  {
+    ScopedTimer tm(c, 1);
+    if (metric == 0)
+      k_finalize<0, false><<<grid, FIN_THREADS, 0, st>>>(f);
+    else if (metric == 1)
+      k_finalize<1, false><<<grid, FIN_THREADS, 0, st>>>(f);
+    else
+      k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
+  }
+  k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(
+    c->d_partials, grid, dst, &c->d_state->done, c->d_counters);
+  LAUNCHCHK();
+  if (c->d_counters)
+    c->counters_clean = true;
+  if (stat && !c->stat_pending)
+  {
+    // what the shortcut's policy looks at, whenever it has arrived
+    k_pass_stat<<<1, 64, 0, st>>>(dst, c->d_counters, c->d_stat);
+    LAUNCHCHK();
+    HIPCHK(hipEventRecord(c->ev_stat, st));
+    c->stat_pending = true;
+  }
+  return ICPX_OK;
+}
+
 extern "C" int icpx_accumulate(icpx_ctx* c, int metric, const double T[16], int64_t step,
   double max_dist, double min_dot, int use_sn, double* sums_host, double* sums_device)
 {
@@ -1299,42 +1533,15 @@ extern "C" int icpx_accumulate(icpx_ctx* c, int metric, const double T[16], int6
   if (rc)
     return rc;
   HIPCHK(hipSetDevice(c->device));
-  rc = prepare_queries(c, step);
+  c->run_active = false;
+  rc = set_transform(c, T, 0);
   if (rc)
     return rc;
   hipStream_t st = c->stream;
   double* dst = sums_device ? sums_device : c->d_sums;
-  if (c->nq == 0)
-  {
-    HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * ICPX_NSUMS, st));
-  }
-  else
-  {
-    rc = run_search(c, T);
-    if (rc)
-      return rc;
-    FinalArgs f;
-    fill_final(c, f, T, max_dist, min_dot, use_sn,
-      use_sn || metric == ICPX_METRIC_PLANE_TO_PLANE);
-    int grid = (int)nblk(c->nq, FIN_THREADS);
-    if (grid > c->max_blocks)
-      grid = c->max_blocks;
-    {
-      ScopedTimer tm(c, 1);
-      if (metric == 0)
-        k_finalize<0, false><<<grid, FIN_THREADS, 0, st>>>(f);
-      else if (metric == 1)
-        k_finalize<1, false><<<grid, FIN_THREADS, 0, st>>>(f);
-      else
-        k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
-    }
-    k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst);
-    LAUNCHCHK();
-    // residual statistics for the next pass's choice of search radius
-    HIPCHK(hipMemcpyAsync(c->h_stat, dst, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(c->ev_stat, st));
-    c->stat_pending = true;
-  }
+  rc = enqueue_pass(c, metric, step, max_dist, min_dot, use_sn, dst, true);
+  if (rc)
+    return rc;
   if (sums_host)
   {
     HIPCHK(hipMemcpyAsync(
@@ -1384,11 +1591,14 @@ extern "C" int icpx_correspond(icpx_ctx* c, const double T[16], int64_t step, do
     ALLOC(c->c_index, nq);
     c->rows_cap = nq;
   }
-  rc = run_search(c, T);
+  c->run_active = false;
+  rc = set_transform(c, T, 0);
+  if (!rc)
+    rc = run_search(c);
   if (rc)
     return rc;
   FinalArgs f;
-  fill_final(c, f, T, max_dist, min_dot, use_sn, use_sn != 0);
+  fill_final(c, f, max_dist, min_dot, use_sn, use_sn != 0);
   f.o_origin = c->r_origin;
   f.o_onormal = use_sn ? c->r_onormal : nullptr;
   f.o_closest = c->r_closest;
@@ -1445,10 +1655,9 @@ extern "C" int icpx_correspond(icpx_ctx* c, const double T[16], int64_t step, do
 }
 
 // ---------------------------------------------------------------- the loop ----
-extern "C" int icpx_run(icpx_ctx* c, const icpx_params* p, double T_out[16], int* iterations_out,
-  double* mean_distance_out, int* status_out)
+static int check_run(icpx_ctx* c, const icpx_params* p)
 {
-  if (!c || !p || !T_out)
+  if (!c || !p)
     return fail(ICPX_E_INVALID, "icpx_run: null argument");
   if (c->nt == 0)
     return fail(ICPX_E_INVALID, "Can't execute with nullptr or empty target");
@@ -1460,24 +1669,161 @@ extern "C" int icpx_run(icpx_ctx* c, const icpx_params* p, double T_out[16], int
     return fail(ICPX_E_INVALID, "Plane to plane metric requires source normals");
   if (p->max_landmarks < 1)
     return fail(ICPX_E_INVALID, "max_landmarks must be positive");
+  return ICPX_OK;
+}
+
+static int64_t landmark_step(const icpx_ctx* c, const icpx_params* p)
+{
+  // vtkPolyDataCorrespondenceFilter.cxx:473-477
+  return c->np > p->max_landmarks ? c->np / p->max_landmarks : 1;
+}
+
+extern "C" int icpx_run_begin(icpx_ctx* c, const icpx_params* p)
+{
+  int rc = check_run(c, p);
+  if (rc)
+    return rc;
+  HIPCHK(hipSetDevice(c->device));
+  c->run_p = *p;
+  c->run_step = landmark_step(c, p);
+  c->run_it = 0;
+  c->run_done_known = false;
+  c->hint_valid = false; // every Update() starts cold
+  c->stat_valid = false;
+  c->stat_pending = false;
+  c->local_holdoff = 0;
+  c->bad_streak = 0;
+  double I[16];
+  for (int i = 0; i < 16; i++)
+    I[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  rc = set_transform(c, I, 1);
+  if (!rc)
+    rc = prepare_queries(c, c->run_step);
+  if (rc)
+    return rc;
+  c->run_active = true;
+  return ICPX_OK;
+}
+
+// The host stays at most two iterations ahead of the device: before iteration i is
+// enqueued, iteration i-2's record (32 bytes, copied behind its solve) is awaited.  That
+// keeps the queue fed, bounds the passes enqueued after the run stopped (they return at
+// once on the device), and brings the residual the shortcut's policy looks at.
+static int run_catch_up(icpx_ctx* c)
+{
+  if (c->run_it < 2)
+    return ICPX_OK;
+  const int slot = (int)((c->run_it - 2) & 3);
+  HIPCHK(hipEventSynchronize(c->ev_rec[slot]));
+  const RunRecord& r = c->h_rec[slot];
+  if (r.done)
+    c->run_done_known = true;
+  note_pass(c, r.n, r.mean, (double)r.fallback);
+  return ICPX_OK;
+}
+
+extern "C" int icpx_run_enqueue(icpx_ctx* c, double* sums_device, int* done_out)
+{
+  if (!c || !c->run_active)
+    return fail(ICPX_E_INVALID, "icpx_run_enqueue: no run in progress (call icpx_run_begin)");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = run_catch_up(c);
+  if (rc)
+    return rc;
+  if (done_out)
+    *done_out = c->run_done_known ? 1 : 0;
+  if (c->run_done_known)
+    return ICPX_OK;
+  const icpx_params& p = c->run_p;
+  return enqueue_pass(c, p.metric, c->run_step, p.max_distance, p.min_normal_dot,
+    p.metric == ICPX_METRIC_PLANE_TO_PLANE ? 1 : 0, sums_device ? sums_device : c->d_sums, false);
+}
+
+extern "C" int icpx_run_update(icpx_ctx* c, const double* sums_device)
+{
+  if (!c || !c->run_active)
+    return fail(ICPX_E_INVALID, "icpx_run_update: no run in progress (call icpx_run_begin)");
+  if (c->run_done_known)
+    return ICPX_OK;
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const icpx_params& p = c->run_p;
+  const int slot = (int)(c->run_it & 3);
+  k_solve<<<1, 64, 0, st>>>(c->d_state, sums_device ? sums_device : c->d_sums, p.metric,
+    c->origin[0], c->origin[1], c->origin[2], p.check_mean_distance, p.max_mean_distance,
+    c->d_counters, c->d_rec + slot);
+  LAUNCHCHK();
+  HIPCHK(hipEventRecord(c->ev_rec[slot], st));
+  c->run_it++;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_run_end(icpx_ctx* c, double T_out[16], int* iterations_out,
+  double* mean_distance_out, int* status_out)
+{
+  if (!c || !c->run_active)
+    return fail(ICPX_E_INVALID, "icpx_run_end: no run in progress (call icpx_run_begin)");
+  HIPCHK(hipSetDevice(c->device));
+  RunState h;
+  HIPCHK(hipMemcpyAsync(&h, c->d_state, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->run_active = false;
+  if (T_out)
+    std::memcpy(T_out, h.T, sizeof(h.T));
+  if (iterations_out)
+    *iterations_out = h.iters;
+  if (mean_distance_out)
+    *mean_distance_out = h.mean;
+  if (status_out)
+    *status_out = h.status;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_run(icpx_ctx* c, const icpx_params* p, double T_out[16], int* iterations_out,
+  double* mean_distance_out, int* status_out)
+{
+  if (!T_out)
+    return fail(ICPX_E_INVALID, "icpx_run: null argument");
+  int rc = check_run(c, p);
+  if (rc)
+    return rc;
+  if (!c->allreduce)
+  {
+    // one rank: nothing leaves the device until the loop is over
+    rc = icpx_run_begin(c, p);
+    for (int it = 0; it < p->max_iterations && !rc; it++)
+    {
+      int done = 0;
+      rc = icpx_run_enqueue(c, nullptr, &done);
+      if (rc || done)
+        break;
+      rc = icpx_run_update(c, nullptr);
+    }
+    if (rc)
+    {
+      c->run_active = false;
+      return rc;
+    }
+    return icpx_run_end(c, T_out, iterations_out, mean_distance_out, status_out);
+  }
+
+  // a host all-reduce hook: sums come to the host every iteration and are solved here
   double T[16];
   for (int i = 0; i < 16; i++)
     T[i] = (i % 5 == 0) ? 1.0 : 0.0;
   c->hint_valid = false; // every Update() starts cold
-  int64_t step = 1;
-  if (c->np > p->max_landmarks)
-    step = c->np / p->max_landmarks; // vtkPolyDataCorrespondenceFilter.cxx:473-477
+  const int64_t step = landmark_step(c, p);
   const int use_sn = p->metric == ICPX_METRIC_PLANE_TO_PLANE ? 1 : 0;
   int iters = 0, status = ICPX_RUN_MAX_ITERATIONS;
   double mean = 0.0;
   double sums[ICPX_NSUMS];
   for (int it = 0; it < p->max_iterations; it++)
   {
-    int rc = icpx_accumulate(
+    rc = icpx_accumulate(
       c, p->metric, T, step, p->max_distance, p->min_normal_dot, use_sn, sums, nullptr);
     if (rc)
       return rc;
-    if (c->allreduce && c->allreduce(sums, ICPX_NSUMS, c->allreduce_user))
+    if (c->allreduce(sums, ICPX_NSUMS, c->allreduce_user))
       return fail(ICPX_E_INVALID, "all-reduce hook reported a failure");
     double M[16];
     int64_t n = 0;

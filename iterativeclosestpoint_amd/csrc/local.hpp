@@ -1,19 +1,21 @@
-// local.hpp — the hinted shortcut: no tree walk when the previous winner is close.
+// local.hpp — the shortcut for queries near the surface: no tree walk.
 //
-// If a query sits within r of its previous winner h (a triangle of leaf l_h), every
-// triangle within r of the query lies in a leaf whose box is within 2r of l_h's
-// box (both closest points are within r of the query).  So for every leaf the
-// list of leaves whose boxes come within eps of it is built once (k_nbr_count /
-// k_nbr_fill: one lane per leaf, a fixed-radius walk of the binary tree), and a
-// hinted query with 2r <= eps only tests that list: a flat loop of box tests with
-// the same trip count for neighbouring lanes, then the usual screening of the few
-// leaves that pass.  Queries whose r is too large (or that have no usable hint)
-// are appended to a list that the tree kernel then serves.  The contenders found
-// are the same as the tree walk's, so the winner is too.
+// If a query sits within r of a triangle h, every triangle within r of the query has
+// its box within 2r of h's box (both closest points are within r of the query).  So
+// for every triangle the list of triangles whose boxes come within eps of its own is
+// built once per target (k_nbr: one lane per triangle, a fixed-radius walk of the
+// one-triangle-per-leaf tree), and a query with 2r <= eps tests only h's list: a flat
+// loop of box tests with similar trip counts for neighbouring lanes, then the usual
+// screening of the few that pass.  The contenders found are the same as a tree walk's,
+// so the winner is too.
+//
+// h is last pass's winner (or, on a cold start, the triangle next to the query on the
+// Morton curve).  When h is too far for that, the query first walks along the surface,
+// from list to list, towards itself; what still does not get within eps/2 of a triangle
+// is appended to a list that the tree kernel then serves.
 //
 // eps is a property of the mesh (a fraction of its typical edge length, chosen by the
-// host so that the lists stay short); the lists are built once per target, the first
-// time the mean residual of a pass has come down to a fraction of eps.
+// host so that the lists stay short).
 #pragma once
 #include "search3.hpp"
 
@@ -102,18 +104,32 @@ __global__ __launch_bounds__(256) void k_nbr(const float* __restrict__ nodes, Bi
 
 struct LocalArgs
 {
-  Search3Args s;        // the tree kernel's arguments (queries, tree, triangles, tie lists)
-  const uint32_t* noff; // neighbour lists, CSR over leaves
+  Search3Args s;        // the tree kernel's arguments (queries, tree, triangles, tie lists);
+                        // nodes/tree are the one-triangle-per-leaf tree the lists index
+  const uint32_t* noff; // neighbour lists, CSR over triangles (Morton positions)
   const int32_t* nbr;
   float eps;            // radius the lists were built for
   uint32_t* fallback;   // queries left to the tree kernel; their count is counters[3]
 };
 
-template <int L>
+constexpr int LOCAL_STEPS = 16; // moves along the surface before a query is given up
+
+// One lane per query.  Start: last pass's winner, or (no winner) the triangle next to the
+// query on the Morton curve.  While the start triangle is too far for its list to hold
+// every contender, the query moves to the listed triangle whose box centre is nearest
+// (a walk along the surface towards the query, strictly downhill in that distance, so it
+// ends); a query that arrives within eps/2 of a triangle is settled from that triangle's
+// list alone, the others are handed to the tree kernel with the triangle they reached as
+// their starting bound.  Every query's slot in hint[] is rewritten.
 __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
 {
   const Search3Args& a = la.s;
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
   __shared__ int32_t ring[RING3][256];
+  __shared__ uint32_t wcount[4];
+  __shared__ uint32_t bbase;
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int64_t q = (int64_t)blockIdx.x * 256 + tid;
@@ -137,53 +153,127 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
     bound = nbound;
     boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
   };
+  auto leaf_box = [&](int32_t m) -> const float* {
+    const uint32_t heap = (1u << d) + (uint32_t)m;
+    return a.nodes + (int64_t)(heap >> 1) * NODE_FLOATS + 6 * (heap & 1u);
+  };
 
   uint32_t e = 0, eend = 0;
   if (active)
   {
-    x = xform(a.T, a.qpos + 3 * q);
+    x = xform(T, a.qpos + 3 * q);
     xf = (float)x.x;
     yf = (float)x.y;
     zf = (float)x.z;
     const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
     eabs = smax * 2.3841858e-07f * 1.0000002f;
     tau = 1e-9 * (double)smax;
-    hs = a.hint[q];
-    if (hs >= 0 && a.tid[hs] >= 0)
+    hs = a.use_hint ? a.hint[q] : -1;
+    if (hs < 0 && a.tcodes)
     {
-      d3 P0, P1, P2;
-      load_tri(a.tverts, hs, P0, P1, P2);
-      set_best(tri_d2_screen(x, P0, P1, P2));
-      // every contender is within r of the query, hence within 2r of the hinted triangle
-      const double r = sqrt(best) + tau;
-      local = 2.0 * r * 1.000001 + 4.0 * (double)eabs <= (double)la.eps;
-      if (local)
+      const uint64_t code = morton63(xf, yf, zf, a.box.lo, a.box.inv);
+      int64_t lo = 0, hi = a.nt; // first position with tcodes[pos] >= code
+      while (lo < hi)
       {
-        const int64_t leaf = hs / L;
-        e = la.noff[leaf];
-        eend = la.noff[leaf + 1];
-        local = eend - e <= NBR_CAP; // a longer list was cut short
+        const int64_t mid = (lo + hi) >> 1;
+        if (a.tcodes[mid] < code)
+          lo = mid + 1;
+        else
+          hi = mid;
       }
-      if (local)
-      {
-        ring[0][tid] = hs;
-        cnt = 1;
-      }
+      hs = (int32_t)min(lo, a.nt - 1);
     }
+    // a triangle can settle the query only if the query is within eps/2 of it; its box
+    // gives a cheap lower bound of that distance
+    const float half = 0.5f * la.eps;
+    const float reach2 = half * half;
+    bool moving = hs >= 0;
+    for (int step = 0; moving; step++)
+    {
+      const float* r = leaf_box(hs);
+      const float2 b0 = *reinterpret_cast<const float2*>(r);
+      const float2 b1 = *reinterpret_cast<const float2*>(r + 2);
+      const float2 b2 = *reinterpret_cast<const float2*>(r + 4);
+      e = la.noff[hs];
+      eend = la.noff[hs + 1];
+      if (eend - e > NBR_CAP)
+        break; // its list was cut short: nothing can be concluded here
+      if (box_lb(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, xf, yf, zf, eabs) <= reach2 &&
+        a.tid[hs] >= 0)
+      {
+        d3 P0, P1, P2;
+        load_tri(a.tverts, hs, P0, P1, P2);
+        const double d2 = tri_d2_screen(x, P0, P1, P2);
+        // every contender is within r of the query, hence within 2r of this triangle
+        const double rr = sqrt(d2) + tau;
+        if (2.0 * rr * 1.000001 + 4.0 * (double)eabs <= (double)la.eps)
+        {
+          best = DBL_MAX;
+          set_best(d2);
+          local = true;
+          break;
+        }
+      }
+      if (step == LOCAL_STEPS)
+        break;
+      // move to the listed triangle whose box centre is nearest to the query
+      float bestc = INFINITY;
+      int32_t bestm = hs;
+      for (uint32_t i = e; i < eend; i += 4)
+      {
+        int32_t m[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          m[k] = la.nbr[min(i + k, eend - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+          const float* rb = leaf_box(m[k]);
+          const float2 c0 = *reinterpret_cast<const float2*>(rb);
+          const float2 c1 = *reinterpret_cast<const float2*>(rb + 2);
+          const float2 c2 = *reinterpret_cast<const float2*>(rb + 4);
+          const float cx = 0.5f * (c0.x + c1.y) - xf, cy = 0.5f * (c0.y + c2.x) - yf,
+                      cz = 0.5f * (c1.x + c2.y) - zf;
+          const float dc = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx));
+          // (strict, and ties to the lower position, so the walk cannot cycle)
+          const bool up = dc < bestc || (dc == bestc && m[k] < bestm);
+          bestc = up ? dc : bestc;
+          bestm = up ? m[k] : bestm;
+        }
+      }
+      if (bestm == hs)
+        moving = false; // nothing listed is nearer: the surface is not within reach here
+      hs = bestm;
+    }
+    if (local)
+    {
+      ring[0][tid] = hs;
+      cnt = 1;
+    }
+    else if (hs >= 0 && a.tid[hs] < 0)
+      hs = -1; // a degenerate triangle is no starting bound for the tree kernel
   }
-  // queries this kernel cannot settle go to the tree kernel
+  // queries this kernel cannot settle go to the tree kernel, with the triangle they
+  // reached as their hint; one atomic per block
   {
     const bool fb = active && !local;
     const unsigned long long mf = __ballot(fb);
-    if (mf)
+    if (lane == 0)
+      wcount[tid >> 6] = (uint32_t)__popcll(mf);
+    __syncthreads();
+    if (tid == 0)
     {
-      const int leader = __ffsll((long long)mf) - 1;
-      uint32_t base = 0;
-      if (lane == leader)
-        base = atomicAdd(&a.counters[3], (uint32_t)__popcll(mf));
-      base = __shfl(base, leader, 64);
-      if (fb)
-        la.fallback[base + __popcll(mf & lt)] = (uint32_t)q;
+      const uint32_t tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+      bbase = tot ? atomicAdd(&a.counters[3], tot) : 0u;
+    }
+    __syncthreads();
+    if (fb)
+    {
+      uint32_t pos = bbase + (uint32_t)__popcll(mf & lt);
+      for (int w = 0; w < (tid >> 6); w++)
+        pos += wcount[w];
+      la.fallback[pos] = (uint32_t)q;
+      a.hint[q] = hs;
     }
   }
 
@@ -200,8 +290,7 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
 #pragma unroll
     for (int k = 0; k < 4; k++)
     {
-      const uint32_t heap = (1u << d) + (uint32_t)m[k];
-      const float* r = a.nodes + (int64_t)(heap >> 1) * NODE_FLOATS + 6 * (heap & 1u);
+      const float* r = leaf_box(m[k]);
       const float2 b0 = *reinterpret_cast<const float2*>(r);
       const float2 b1 = *reinterpret_cast<const float2*>(r + 2);
       const float2 b2 = *reinterpret_cast<const float2*>(r + 4);
@@ -216,29 +305,20 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
     {
       const int k = __ffs((int)pass) - 1;
       pass &= pass - 1;
-      const int32_t cur = (k == 0) ? m[0] : (k == 1) ? m[1] : (k == 2) ? m[2] : m[3];
+      const int32_t s = (k == 0) ? m[0] : (k == 1) ? m[1] : (k == 2) ? m[2] : m[3];
       const float lbk = (k == 0) ? lb[0] : (k == 1) ? lb[1] : (k == 2) ? lb[2] : lb[3];
-      if (lbk > boundf)
-        continue; // the bound tightened since the test
-      const int64_t s0 = (int64_t)cur * L;
-#pragma unroll
-      for (int t = 0; t < L; t++)
+      if (lbk > boundf || s == hs || a.tid[s] < 0)
+        continue; // the bound tightened since the test / the centre itself / degenerate
+      d3 P0, P1, P2;
+      load_tri(a.tverts, s, P0, P1, P2);
+      const double d2 = tri_d2_screen(x, P0, P1, P2);
+      if (d2 < best)
+        set_best(d2);
+      if (d2 <= bound)
       {
-        const int64_t s = s0 + t;
-        if (s < a.nt && a.tid[s] >= 0 && (int32_t)s != hs)
-        {
-          d3 P0, P1, P2;
-          load_tri(a.tverts, s, P0, P1, P2);
-          const double d2 = tri_d2_screen(x, P0, P1, P2);
-          if (d2 < best)
-            set_best(d2);
-          if (d2 <= bound)
-          {
-            if (cnt < RING3)
-              ring[cnt][tid] = (int32_t)s;
-            cnt++;
-          }
-        }
+        if (cnt < RING3)
+          ring[cnt][tid] = s;
+        cnt++;
       }
     }
   }

@@ -32,6 +32,33 @@ struct Xf
   double m[12]; // rows 0..2 of the 4x4
 };
 
+// How a kernel receives the transform: a row-major 4x4 in device memory (so that a loop
+// whose solve runs on the device never brings it to the host), and the flag that tells a
+// pass enqueued ahead of time that its registration has stopped in the meantime.
+struct XfRef
+{
+  const double* T;
+  const int32_t* stop;
+};
+
+__device__ __forceinline__ double uniform_f64(double v)
+{
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// Loads the transform into scalar registers; false when the pass must not run.
+__device__ __forceinline__ bool load_xf(const XfRef& r, Xf& out)
+{
+  if (r.stop && __builtin_amdgcn_readfirstlane(*r.stop) != 0)
+    return false;
+#pragma unroll
+  for (int i = 0; i < 12; i++)
+    out.m[i] = uniform_f64(r.T[i]);
+  return true;
+}
+
 // vtkTransform::InternalTransformPoint on a float point promoted to double
 // (ICP/vtkPolyDataCorrespondenceFilter.cxx:116-119).
 __device__ __forceinline__ d3 xform(const Xf& T, const float* __restrict__ p)
@@ -60,7 +87,7 @@ struct SearchArgs
 {
   const float* qpos; // query points in query-Morton order
   int64_t nq;
-  Xf T;
+  XfRef T;
   const float* nodes;
   TreeLevels lv;
   const float* tverts;
@@ -82,6 +109,9 @@ struct SearchCfg
 template <int G>
 __global__ __launch_bounds__(256) void k_search(SearchArgs a)
 {
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
   using Cfg = SearchCfg<G>;
   __shared__ unsigned long long stack[Cfg::GPB][Cfg::STACK];
   __shared__ int64_t s_off[MAXLEV + 1];
@@ -105,7 +135,7 @@ __global__ __launch_bounds__(256) void k_search(SearchArgs a)
   int top = 0;
   if (active)
   {
-    x = xform(a.T, a.qpos + 3 * q);
+    x = xform(T, a.qpos + 3 * q);
     if (a.use_hint)
     {
       int32_t hs = a.hint[q];
@@ -226,7 +256,7 @@ struct FinalArgs
   const float* qsn;    // sorted source normals (or null)
   const int32_t* qk;   // sorted position -> kept index local to the shard
   int64_t nq;
-  Xf T;
+  XfRef T;
   double origin[3];
   const float* tverts;
   const int32_t* tid;
@@ -334,6 +364,9 @@ constexpr int FIN_THREADS = 256;
 template <int METRIC, bool ROWS>
 __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalArgs a)
 {
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
   constexpr int NS = SumCfg<METRIC>::N;
   double acc[NS];
 #pragma unroll
@@ -343,7 +376,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalArgs a)
   const int64_t stride = (int64_t)gridDim.x * FIN_THREADS;
   for (int64_t p = (int64_t)blockIdx.x * FIN_THREADS + threadIdx.x; p < a.nq; p += stride)
   {
-    const d3 x = xform(a.T, a.qpos + 3 * p);
+    const d3 x = xform(T, a.qpos + 3 * p);
     const int32_t hs = a.hint[p];
     const int64_t k = a.qk[p];
     bool accept = false;
@@ -454,9 +487,19 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalArgs a)
 // partials l, l+64, ... in that order, then a fixed xor-shuffle tree; the shape
 // depends only on the number of blocks, so results repeat run to run.
 __global__ __launch_bounds__(64) void k_reduce_partials(
-  const double* __restrict__ partials, int nblocks, double* __restrict__ sums)
+  const double* __restrict__ partials, int nblocks, double* __restrict__ sums,
+  const int32_t* __restrict__ stop, uint32_t* __restrict__ counters)
 {
+  if (stop && *stop)
+    return; // the pass did not run
   const int i = blockIdx.x, l = threadIdx.x;
+  if (counters && i == 0 && l < 4)
+  {
+    // the search kernels' four pass counters move up for whoever wants to look at them,
+    // and are left at zero for the next pass
+    counters[4 + l] = counters[l];
+    counters[l] = 0u;
+  }
   double v = 0.0;
   for (int b = l; b < nblocks; b += 64)
     v += partials[(int64_t)b * ICPX_NSUMS + i];

@@ -295,7 +295,7 @@ struct Search2Args
 {
   const float* qpos;
   int64_t nq;
-  Xf T;
+  XfRef T;
   const float* nodes;
   HeapTree tree;
   const float* tverts;
@@ -318,6 +318,9 @@ struct Search2Cfg
 template <int G>
 __global__ __launch_bounds__(256) void k_search2(Search2Args a)
 {
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
   using Cfg = Search2Cfg<G>;
   __shared__ unsigned long long stack[Cfg::GPB][Cfg::STACK];
   __shared__ int32_t ring[Cfg::GPB][Cfg::RING];
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(256) void k_search2(Search2Args a)
 
   if (active)
   {
-    x = xform(a.T, a.qpos + 3 * q);
+    x = xform(T, a.qpos + 3 * q);
     xf = (float)x.x;
     yf = (float)x.y;
     zf = (float)x.z;

@@ -108,7 +108,7 @@ struct Search3Args
 {
   const float* qpos;
   int64_t nq;
-  Xf T;
+  XfRef T;
   const float* nodes;
   BinTree tree;
   const float* tverts;
@@ -143,6 +143,9 @@ __device__ __forceinline__ float box_lb(float lox, float loy, float loz, float h
 template <int L, bool EXACT>
 __global__ __launch_bounds__(256) void k_search3(Search3Args a)
 {
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
   __shared__ int32_t ring[RING3][256];
   const int tid = threadIdx.x;
   int64_t q = (int64_t)blockIdx.x * 256 + tid;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void k_search3(Search3Args a)
 
   if (active)
   {
-    x = xform(a.T, a.qpos + 3 * q);
+    x = xform(T, a.qpos + 3 * q);
     xf = (float)x.x;
     yf = (float)x.y;
     zf = (float)x.z;
@@ -383,6 +386,9 @@ constexpr int REFILL3 = 16;
 template <int L>
 __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
 {
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
   __shared__ int32_t ring[RING3][256];
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
           best = DBL_MAX;
           bound = DBL_MAX;
           boundf = FLT_MAX;
-          x = xform(a.T, a.qpos + 3 * q);
+          x = xform(T, a.qpos + 3 * q);
           xf = (float)x.x;
           yf = (float)x.y;
           zf = (float)x.z;
@@ -605,6 +611,9 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
 // evaluation, (dist2, cell id) minimum by DPP exchanges.
 __global__ __launch_bounds__(256) void k_resolve_ties(Search3Args a)
 {
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
   const uint32_t total = a.counters[0];
   const int j = threadIdx.x & 7;
   const uint32_t ngroups = gridDim.x * 32u;
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(256) void k_resolve_ties(Search3Args a)
     if (j < (int)rec.y)
     {
       s = a.cand[q * RING3 + j];
-      const d3 x = xform(a.T, a.qpos + 3 * q);
+      const d3 x = xform(T, a.qpos + 3 * q);
       d3 P0, P1, P2, cp;
       double dd, w[3];
       load_tri(a.tverts, s, P0, P1, P2);

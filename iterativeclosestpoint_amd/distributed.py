@@ -77,6 +77,26 @@ class ShardedICP:
         ar = make_allreduce(self.group)
         return sums if ar is None else ar(sums)
 
+    def run_device(self, params):
+        """The whole loop without a host round trip per iteration: search and sums on the
+        GPU, all-reduce of the 40 sums on the device (stream-ordered, RCCL), solve and
+        transform update on the device.  Needs the device all-reduce buffer (the default).
+        Returns (T 4x4, iterations, mean_distance, status), the same on every rank."""
+        import torch.distributed as dist
+
+        assert self.sums_dev is not None, "run_device needs use_device_allreduce=True"
+        multi = dist.is_available() and dist.is_initialized() and \
+            dist.get_world_size(self.group) > 1
+        ptr = self.sums_dev.data_ptr()
+        self.ctx.run_begin(params)
+        for _ in range(params.max_iterations):
+            if self.ctx.run_enqueue(ptr):
+                break
+            if multi:
+                dist.all_reduce(self.sums_dev, op=dist.ReduceOp.SUM, group=self.group)
+            self.ctx.run_update(ptr)
+        return self.ctx.run_end()
+
     def run(self, metric=1, max_iterations=50, max_landmarks=200, max_distance=10.0,
             check_mean_distance=False, max_mean_distance=0.01, min_normal_dot=0.0, n_points=None):
         npts = n_points if n_points is not None else self.ctx._np

@@ -26,6 +26,7 @@ SYMBOLS = (
     "icpx_set_allreduce", "icpx_run", "icpx_last_build_seconds", "icpx_set_group_width",
     "icpx_reset_hints", "icpx_set_timing", "icpx_get_timing", "icpx_set_exhaustive",
     "icpx_set_leaf_size", "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local",
+    "icpx_run_begin", "icpx_run_enqueue", "icpx_run_update", "icpx_run_end",
 )
 
 
@@ -76,6 +77,10 @@ def load():
     lib.icpx_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
     lib.icpx_run.argtypes = [vp, C.POINTER(Params), vp, C.POINTER(ci), C.POINTER(dbl),
                              C.POINTER(ci)]
+    lib.icpx_run_begin.argtypes = [vp, C.POINTER(Params)]
+    lib.icpx_run_enqueue.argtypes = [vp, vp, C.POINTER(ci)]
+    lib.icpx_run_update.argtypes = [vp, vp]
+    lib.icpx_run_end.argtypes = [vp, vp, C.POINTER(ci), C.POINTER(dbl), C.POINTER(ci)]
     lib.icpx_last_build_seconds.argtypes = [vp]
     lib.icpx_last_build_seconds.restype = dbl
     lib.icpx_set_group_width.argtypes = [vp, ci]
@@ -278,6 +283,29 @@ class Context:
                     return 1
             self._cb = ALLREDUCE_FN(tramp)
         _chk(load().icpx_set_allreduce(self._h, self._cb, None))
+
+    def run_begin(self, params):
+        """Start a device-resident registration (see run_enqueue / run_update / run_end)."""
+        _chk(load().icpx_run_begin(self._h, C.byref(params)))
+
+    def run_enqueue(self, device_ptr=None):
+        """Enqueue one iteration's search + sums (into the device buffer at `device_ptr`, or
+        an internal one).  Returns True once the run is known to have stopped."""
+        done = C.c_int(0)
+        _chk(load().icpx_run_enqueue(self._h, C.c_void_p(device_ptr) if device_ptr else None,
+                                     C.byref(done)))
+        return bool(done.value)
+
+    def run_update(self, device_ptr=None):
+        """Enqueue the solve + transform update of the iteration on the (reduced) sums."""
+        _chk(load().icpx_run_update(self._h, C.c_void_p(device_ptr) if device_ptr else None))
+
+    def run_end(self):
+        """Wait for the run; returns (T 4x4, iterations, mean_distance, status)."""
+        T = np.zeros(16)
+        it, st, md = C.c_int(0), C.c_int(0), C.c_double(0)
+        _chk(load().icpx_run_end(self._h, _p(T), C.byref(it), C.byref(md), C.byref(st)))
+        return T.reshape(4, 4), it.value, md.value, st.value
 
     def run(self, params):
         """Whole vtkICP loop on this context. Returns (T 4x4, iterations, mean_distance, status)."""

@@ -187,6 +187,38 @@ def test_icp_run_matches_oracle(icpx, synth, small, metric, landmarks):
     assert rel_err(T, T32) <= 2e-4
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_device_loop_matches_host_loop(icpx, synth, small, metric):
+    """The device-resident loop (solve, transform and stop test on the GPU) takes the same
+    steps as the loop that brings the sums to the host every iteration, including the early
+    stop, for a run driven through run_begin/enqueue/update/end as a multi-GPU driver does."""
+    c, mesh = small
+    sn = synth.vertex_normals(c["source_xyz"], c["target_tri"]) if metric == 2 else None
+    ctx = icpx.Context(0)
+    ctx.set_target(c["target_xyz"], c["target_tri"])
+    ctx.set_source(c["source_xyz"], sn)
+    for check in (0, 1):
+        p = icpx.default_params()
+        p.metric, p.max_iterations, p.max_landmarks = metric, 40, 2000
+        p.max_distance = c2_threshold(synth, c)
+        p.check_mean_distance, p.max_mean_distance = check, 2e-3
+        Td, itd, md, std = ctx.run(p)                      # device loop
+        ctx.set_allreduce(lambda sums: sums)               # a host hook selects the host loop
+        Th, ith, mh, sth = ctx.run(p)
+        ctx.set_allreduce(None)
+        assert (itd, std) == (ith, sth)
+        assert check == 0 or (std == 1 and itd < 40)
+        assert rel_err(Td, Th) <= 1e-12 and abs(md - mh) <= 1e-12 * max(1.0, abs(mh))
+        ctx.run_begin(p)                                   # the same, driven step by step
+        for _ in range(p.max_iterations):
+            if ctx.run_enqueue():
+                break
+            ctx.run_update()
+        Ts, its, ms, sts = ctx.run_end()
+        assert (its, sts) == (itd, std) and np.array_equal(Ts, Td) and ms == md
+
+
 def c2_threshold(synth, c):
     return 0.25 * synth.diag(c["target_xyz"])
 
@@ -422,11 +454,13 @@ def test_hinted_shortcut_matches_tree_walk(icpx, synth, oracle):
         c.set_target(xyz, tri)
         c.set_source(src)
         ctxs.append(c)
-    for T in seq:
+    for i, T in enumerate(seq):
+        if i == 3:
+            ctxs[0].set_local(True)  # two far passes in a row suspend the shortcut: start afresh
         sums = [c.accumulate(1, T, step=1, max_dist=0.05) for c in ctxs]
         assert np.array_equal(sums[0], sums[1]) and np.array_equal(sums[1], sums[2])
     st = ctxs[0].debug_stats()
-    assert st["local_passes"] >= 3 and st["nbr_builds"] >= 1, st
+    assert st["local_passes"] >= 4 and st["nbr_builds"] >= 1, st
     assert ctxs[1].debug_stats()["local_passes"] == 0
     mesh = oracle.Mesh(xyz, tri)
     ref = mesh.correspond(src, T=Tinv, step=1, max_dist=0.05, grid=True)

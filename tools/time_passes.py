@@ -35,6 +35,7 @@ def main():
         ctx.accumulate(metric, np.eye(4), 1, c["max_dist"])  # builds tree, sorts queries
 
         def timed(T, reset):
+            ctx.set_local(a.local)  # the shortcut's policy starts afresh for every phase
             ts = []
             for _ in range(a.reps):
                 if reset:
