@@ -670,6 +670,19 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
   return ICPX_OK;
 }
 
+#ifdef ICPX_STATS
+// development build only: read and clear the traversal statistics
+extern "C" int icpx_stats_read(icpx_ctx* c, unsigned long long out[8])
+{
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(icpx::g_stats), sizeof(unsigned long long) * 8));
+  unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(icpx::g_stats), z, sizeof(z)));
+  return ICPX_OK;
+}
+#endif
+
 extern "C" int icpx_set_leaf_size(icpx_ctx* c, int triangles)
 {
   if (!c)

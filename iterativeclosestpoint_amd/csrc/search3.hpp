@@ -378,6 +378,15 @@ __global__ __launch_bounds__(256) void k_search3(Search3Args a)
 // one query per lane for the lifetime of a wavefront most lanes sit idle waiting
 // for the slowest; refilling keeps them busy.  Results are per query and do not
 // depend on which lane ran them.  counters[2] is the pool's next query.
+#ifdef ICPX_STATS
+// development build only: totals over all queries of {node visits, leaves screened, visits that rejected both children,
+// triangle screens, loop iterations (per wavefront), refills}
+__device__ unsigned long long g_stats[8];
+#define STAT(i, v) st_##i += (v)
+#else
+#define STAT(i, v)
+#endif
+
 constexpr int REFILL3 = 16;
 #ifndef LEAFGO3
 #define LEAFGO3 24
@@ -408,6 +417,9 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
   const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
   if ((int64_t)blockIdx.x * 256 >= total)
     return; // a short list is served by the first blocks; the rest must not queue at the pool
+#ifdef ICPX_STATS
+  unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0;
+#endif
 
   auto set_best = [&](double nb) {
     const double r = sqrt(nb) + tau;
@@ -523,9 +535,11 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
         }
         dry = __ballot(want && nq_ >= total) != 0ull;
       }
+      STAT(5, lane == 0 ? 1 : 0);
       if (__ballot(have) == 0ull)
         break;
     }
+    STAT(4, lane == 0 ? 1 : 0);
 
     // one step of the walk for every lane that is between leaves (see k_search3)
     if (have && !fin && !atleaf)
@@ -552,6 +566,7 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
       }
       if (!fin && !need_bt && !atleaf)
       {
+        STAT(0, 1);
         const float4* p = reinterpret_cast<const float4*>(a.nodes + (int64_t)n * NODE_FLOATS);
         const float4 u = p[0], v = p[1], w = p[2];
         const float lb0 = box_lb(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf, eabs);
@@ -570,7 +585,10 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
           atleaf = (lvl == d - 1);
         }
         else
+        {
+          STAT(2, 1);
           need_bt = true;
+        }
       }
     }
 
@@ -581,6 +599,7 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
     const bool anywalk = __ballot(have && !fin && !atleaf) != 0ull;
     if (onleaf && (nleaf >= LEAFGO3 || !anywalk))
     {
+      STAT(1, 1);
       const int64_t s0 = (int64_t)(n - (1u << d)) * L;
 #pragma unroll
       for (int t = 0; t < L; t++)
@@ -588,6 +607,7 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
         const int64_t s = s0 + t;
         if (s < a.nt && a.tid[s] >= 0)
         {
+          STAT(3, 1);
           d3 P0, P1, P2;
           load_tri(a.tverts, s, P0, P1, P2);
           const double d2 = tri_d2_screen(x, P0, P1, P2);
@@ -605,6 +625,14 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
       atleaf = false;
     }
   }
+#ifdef ICPX_STATS
+  atomicAdd(&g_stats[0], st_0);
+  atomicAdd(&g_stats[1], st_1);
+  atomicAdd(&g_stats[2], st_2);
+  atomicAdd(&g_stats[3], st_3);
+  atomicAdd(&g_stats[4], st_4);
+  atomicAdd(&g_stats[5], st_5);
+#endif
 }
 
 // Contested queries: eight lanes per query, one contender per lane, exact

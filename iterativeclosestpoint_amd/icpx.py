@@ -17,7 +17,7 @@ E_INVALID, E_HIP, E_NOMEM, E_FEW = -1, -2, -3, -4
 RUN_MAX_ITERATIONS, RUN_CONVERGED, RUN_TOO_FEW = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libicpx.so")
+LIB_PATH = os.environ.get("ICPX_LIB") or os.path.join(_HERE, "libicpx.so")  # (ICPX_LIB: development builds)
 
 SYMBOLS = (
     "icpx_last_error", "icpx_device_count", "icpx_create", "icpx_destroy", "icpx_set_stream",

@@ -10,6 +10,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from iterativeclosestpoint_amd import icpx, synth  # noqa: E402
 
 
+def stats_read(ctx):
+    """Traversal statistics of a development build (make -C .../csrc stats; ICPX_LIB=...)."""
+    import ctypes
+    lib = icpx.load()
+    if not hasattr(lib, "icpx_stats_read"):
+        return None
+    out = (ctypes.c_ulonglong * 8)()
+    lib.icpx_stats_read(ctypes.c_void_p(ctx._h.value if hasattr(ctx._h, "value") else ctx._h), out)
+    return list(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c3")
@@ -37,6 +48,7 @@ def main():
         def timed(T, reset):
             ctx.set_local(a.local)  # the shortcut's policy starts afresh for every phase
             ts = []
+            stats_read(ctx)
             for _ in range(a.reps):
                 if reset:
                     ctx.reset_hints()
@@ -44,6 +56,13 @@ def main():
                 ctx.accumulate(metric, T, 1, c["max_dist"])
                 s_ms, s_n, f_ms, f_n = ctx.get_timing()
                 ts.append(s_ms)
+            st = stats_read(ctx)
+            if st is not None:
+                nq = len(c["source_xyz"]) * a.reps
+                print("   per query: node visits %.1f (wasted %.1f)  leaves %.1f  screens %.1f;"
+                      "  per wavefront: loop trips %.0f refills %.1f" %
+                      (st[0] / nq, st[2] / nq, st[1] / nq, st[3] / nq, st[4] / (nq / 64),
+                       st[5] / (nq / 64)))
             return min(ts), float(np.median(ts))
         cold = timed(np.eye(4), True)
         hot0 = timed(np.eye(4), False)
