@@ -192,6 +192,7 @@ struct icpx_ctx
   float* d_tverts = nullptr;
   int32_t* d_tid = nullptr;
   uint64_t* d_tcodes = nullptr; // sorted Morton codes of the triangles
+  float4* d_tpre = nullptr;     // per-triangle plane bounds
   float *d_fn = nullptr, *d_en = nullptr, *d_vn = nullptr;
   Box3 box;
   double origin[3] = { 0, 0, 0 };
@@ -209,6 +210,8 @@ struct icpx_ctx
   float mesh_edge = 0.f; // typical edge length of the target (sampled)
   uint32_t* d_noff = nullptr;
   int32_t* d_nbr = nullptr;
+  uint4* d_qbox = nullptr; // quantised leaf boxes of the one-triangle-per-leaf tree
+  QuantGrid qgrid;
   uint32_t* d_fallback = nullptr;
   double* h_stat = nullptr; // pinned {n, sum |s-t|, shortcut fallbacks} of a finished pass
   hipEvent_t ev_stat = nullptr;
@@ -399,6 +402,7 @@ static void free_target(icpx_ctx* c)
   dev_free(&c->d_tverts);
   dev_free(&c->d_tid);
   dev_free(&c->d_tcodes);
+  dev_free(&c->d_tpre);
   dev_free(&c->d_fn);
   dev_free(&c->d_en);
   dev_free(&c->d_vn);
@@ -419,6 +423,7 @@ static void free_target(icpx_ctx* c)
   }
   dev_free(&c->d_noff);
   dev_free(&c->d_nbr);
+  dev_free(&c->d_qbox);
   c->nbr_eps = 0.f;
   c->nbr_state = 0;
   c->stat_valid = false;
@@ -707,7 +712,7 @@ extern "C" int icpx_set_persistent(icpx_ctx* c, int enable)
 {
   if (!c)
     return fail(ICPX_E_INVALID, "null context");
-  c->persistent = enable ? 1 : 0;
+  c->persistent = enable < 0 ? 0 : enable > 2 ? 2 : enable;
   return ICPX_OK;
 }
 
@@ -849,6 +854,8 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
     rc = dev_alloc(&c->d_tverts, 9 * nt);
   if (!rc)
     rc = dev_alloc(&c->d_tid, nt);
+  if (!rc)
+    rc = dev_alloc(&c->d_tpre, 2 * nt);
   auto drop_sort = [&]() {
     dev_free(&k0);
     dev_free(&k1);
@@ -866,6 +873,7 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   k_gather_tris<<<nblk(nt, 256), 256, 0, st>>>(
     c->d_xyz, c->d_tri, which ? v1 : v0, nt, c->d_tverts, c->d_tid);
   k_flag_degenerate<<<nblk(nt, 256), 256, 0, st>>>(c->d_tverts, nt, c->d_tid);
+  k_tri_bounds<<<nblk(nt, 256), 256, 0, st>>>(c->d_tverts, nt, c->d_tpre);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && dev_alloc(&c->d_tcodes, nt) == ICPX_OK)
     e = hipMemcpyAsync(
@@ -1153,9 +1161,12 @@ static int ensure_bin(icpx_ctx* c, int L)
 }
 
 template <int L>
-static void launch_search3(const Search3Args& a, unsigned grid, unsigned pgrid, hipStream_t st)
+static void launch_search3(
+  const Search3Args& a, unsigned grid, unsigned pgrid, bool queued, hipStream_t st)
 {
-  if (pgrid)
+  if (pgrid && queued)
+    k_search3q<L><<<pgrid, 256, 0, st>>>(a);
+  else if (pgrid)
     k_search3p<L><<<pgrid, 256, 0, st>>>(a);
   else
     k_search3<L, false><<<grid, 256, 0, st>>>(a);
@@ -1200,6 +1211,14 @@ static int build_nbr(icpx_ctx* c, const Bin& b, float eps)
   }
   ALLOC(c->d_nbr, (int64_t)total + 4);
   k_nbr<true><<<nblk(nl, 256), 256, 0, st>>>(b.nodes, b.t, eps2, nullptr, c->d_noff, c->d_nbr);
+  ALLOC(c->d_qbox, nl);
+  for (int a = 0; a < 3; a++)
+  {
+    const float ext = c->box.inv[a] > 0.f ? 1.f / c->box.inv[a] : 0.f;
+    c->qgrid.base[a] = c->box.lo[a];
+    c->qgrid.step[a] = std::fmax(ext * 1.000001f, 1e-30f) / 65535.f;
+  }
+  k_quant_boxes<<<nblk(nl, 256), 256, 0, st>>>(b.nodes, b.t, c->qgrid, c->d_qbox);
   LAUNCHCHK();
   c->nbr_eps = eps;
   return ICPX_OK;
@@ -1297,6 +1316,7 @@ static int run_search3(icpx_ctx* c)
   a.tree = b.t;
   a.tverts = c->d_tverts;
   a.tid = c->d_tid;
+  a.tpre = c->d_tpre;
   a.nt = c->nt;
   a.hint = c->d_hint;
   a.use_hint = c->hint_valid ? 1 : 0;
@@ -1327,6 +1347,8 @@ static int run_search3(icpx_ctx* c)
     la.s.tree = c->bins[0].t;
     la.noff = c->d_noff;
     la.nbr = c->d_nbr;
+    la.qbox = c->d_qbox;
+    la.grid = c->qgrid;
     la.eps = c->nbr_eps;
     la.fallback = c->d_fallback;
     k_search_local<<<grid, 256, 0, st>>>(la);
@@ -1345,11 +1367,11 @@ static int run_search3(icpx_ctx* c)
       pgrid = grid;
   }
   if (L == 1)
-    launch_search3<1>(a, grid, pgrid, st);
+    launch_search3<1>(a, grid, pgrid, c->persistent == 2, st);
   else if (L == 2)
-    launch_search3<2>(a, grid, pgrid, st);
+    launch_search3<2>(a, grid, pgrid, c->persistent == 2, st);
   else
-    launch_search3<4>(a, grid, pgrid, st);
+    launch_search3<4>(a, grid, pgrid, c->persistent == 2, st);
   LAUNCHCHK();
   c->hint_valid = true;
   return ICPX_OK;

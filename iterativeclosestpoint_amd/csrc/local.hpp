@@ -38,7 +38,8 @@ __device__ __forceinline__ float box_box_lb(const float* __restrict__ A, float b
 constexpr uint32_t NBR_CAP = 96;
 
 // One lane per leaf: all leaves whose boxes come within sqrt(eps2) of it.
-// FILL = false counts them, FILL = true writes them at off[leaf].
+// FILL = false counts them, FILL = true writes them at off[leaf].  Lists are padded with
+// -1 to a multiple of four entries, so that the search reads them as aligned int4.
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_nbr(const float* __restrict__ nodes, BinTree t,
   float eps2, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
@@ -98,16 +99,63 @@ __global__ __launch_bounds__(256) void k_nbr(const float* __restrict__ nodes, Bi
         need_bt = true;
     }
   }
+  const uint32_t padded = (count + 3u) & ~3u;
   if (!FILL)
-    cnt[i] = count;
+    cnt[i] = padded;
+  else
+    for (uint32_t j = count; j < padded; j++)
+      nbr[base + j] = -1;
+}
+
+// Leaf boxes on a 16-bit grid over the target's bounds, rounded outwards by one extra
+// step, six values packed into one 16-byte record: the search reads a neighbour's box
+// with a single load.  A box test on the looser box can only admit more triangles.
+struct QuantGrid
+{
+  float base[3], step[3];
+};
+
+__global__ void k_quant_boxes(const float* __restrict__ nodes, BinTree t, QuantGrid g,
+  uint4* __restrict__ out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t.nleaf)
+    return;
+  const uint32_t self = (1u << t.depth) + (uint32_t)i;
+  const float* r = nodes + (int64_t)(self >> 1) * NODE_FLOATS + 6 * (self & 1u);
+  uint32_t q[6];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+  {
+    const double lo = floor(((double)r[a] - (double)g.base[a]) / (double)g.step[a]) - 1.0;
+    const double hi = ceil(((double)r[3 + a] - (double)g.base[a]) / (double)g.step[a]) + 1.0;
+    q[a] = (uint32_t)fmin(fmax(lo, 0.0), 65535.0);
+    q[3 + a] = (uint32_t)fmin(fmax(hi, 0.0), 65535.0);
+  }
+  out[i] = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), 0u);
+}
+
+// lower bound of the squared distance from the query to a quantised leaf box
+__device__ __forceinline__ float qbox_lb(const uint4 w, const QuantGrid& g, float xf, float yf,
+  float zf, float eabs)
+{
+  const float lox = __builtin_fmaf((float)(w.x & 0xffffu), g.step[0], g.base[0]);
+  const float loy = __builtin_fmaf((float)(w.x >> 16), g.step[1], g.base[1]);
+  const float loz = __builtin_fmaf((float)(w.y & 0xffffu), g.step[2], g.base[2]);
+  const float hix = __builtin_fmaf((float)(w.y >> 16), g.step[0], g.base[0]);
+  const float hiy = __builtin_fmaf((float)(w.z & 0xffffu), g.step[1], g.base[1]);
+  const float hiz = __builtin_fmaf((float)(w.z >> 16), g.step[2], g.base[2]);
+  return box_lb(lox, loy, loz, hix, hiy, hiz, xf, yf, zf, eabs);
 }
 
 struct LocalArgs
 {
   Search3Args s;        // the tree kernel's arguments (queries, tree, triangles, tie lists);
                         // nodes/tree are the one-triangle-per-leaf tree the lists index
-  const uint32_t* noff; // neighbour lists, CSR over triangles (Morton positions)
-  const int32_t* nbr;
+  const uint32_t* noff; // neighbour lists, CSR over triangles (Morton positions); every
+  const int32_t* nbr;   // list starts on a multiple of four entries and is padded with -1
+  const uint4* qbox;    // quantised leaf boxes
+  QuantGrid grid;
   float eps;            // radius the lists were built for
   uint32_t* fallback;   // queries left to the tree kernel; their count is counters[3]
 };
@@ -134,7 +182,6 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int64_t q = (int64_t)blockIdx.x * 256 + tid;
   const bool active = q < a.nq;
-  const int d = a.tree.depth;
 
   d3 x = mk(0.0, 0.0, 0.0);
   float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f;
@@ -152,10 +199,6 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
     best = nb;
     bound = nbound;
     boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
-  };
-  auto leaf_box = [&](int32_t m) -> const float* {
-    const uint32_t heap = (1u << d) + (uint32_t)m;
-    return a.nodes + (int64_t)(heap >> 1) * NODE_FLOATS + 6 * (heap & 1u);
   };
 
   uint32_t e = 0, eend = 0;
@@ -187,19 +230,18 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
     // gives a cheap lower bound of that distance
     const float half = 0.5f * la.eps;
     const float reach2 = half * half;
+    const float gsx = la.grid.step[0], gsy = la.grid.step[1], gsz = la.grid.step[2];
+    const float qx2 = 2.f * (xf - la.grid.base[0]), qy2 = 2.f * (yf - la.grid.base[1]),
+                qz2 = 2.f * (zf - la.grid.base[2]);
     bool moving = hs >= 0;
     for (int step = 0; moving; step++)
     {
-      const float* r = leaf_box(hs);
-      const float2 b0 = *reinterpret_cast<const float2*>(r);
-      const float2 b1 = *reinterpret_cast<const float2*>(r + 2);
-      const float2 b2 = *reinterpret_cast<const float2*>(r + 4);
+      const uint4 wb = la.qbox[hs];
       e = la.noff[hs];
       eend = la.noff[hs + 1];
       if (eend - e > NBR_CAP)
         break; // its list was cut short: nothing can be concluded here
-      if (box_lb(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, xf, yf, zf, eabs) <= reach2 &&
-        a.tid[hs] >= 0)
+      if (qbox_lb(wb, la.grid, xf, yf, zf, eabs) <= reach2 && a.tid[hs] >= 0)
       {
         d3 P0, P1, P2;
         load_tri(a.tverts, hs, P0, P1, P2);
@@ -221,22 +263,22 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
       int32_t bestm = hs;
       for (uint32_t i = e; i < eend; i += 4)
       {
-        int32_t m[4];
+        const int4 m4 = *reinterpret_cast<const int4*>(la.nbr + i);
+        const int32_t m[4] = { m4.x, m4.y, m4.z, m4.w };
+        uint4 wq[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          m[k] = la.nbr[min(i + k, eend - 1)];
+          wq[k] = la.qbox[max(m[k], 0)];
 #pragma unroll
         for (int k = 0; k < 4; k++)
         {
-          const float* rb = leaf_box(m[k]);
-          const float2 c0 = *reinterpret_cast<const float2*>(rb);
-          const float2 c1 = *reinterpret_cast<const float2*>(rb + 2);
-          const float2 c2 = *reinterpret_cast<const float2*>(rb + 4);
-          const float cx = 0.5f * (c0.x + c1.y) - xf, cy = 0.5f * (c0.y + c2.x) - yf,
-                      cz = 0.5f * (c1.x + c2.y) - zf;
+          // twice the box centre, in grid steps, against twice the query
+          const float cx = ((float)(wq[k].x & 0xffffu) + (float)(wq[k].y >> 16)) * gsx - qx2;
+          const float cy = ((float)(wq[k].x >> 16) + (float)(wq[k].z & 0xffffu)) * gsy - qy2;
+          const float cz = ((float)(wq[k].y & 0xffffu) + (float)(wq[k].z >> 16)) * gsz - qz2;
           const float dc = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx));
           // (strict, and ties to the lower position, so the walk cannot cycle)
-          const bool up = dc < bestc || (dc == bestc && m[k] < bestm);
+          const bool up = m[k] >= 0 && (dc < bestc || (dc == bestc && m[k] < bestm));
           bestc = up ? dc : bestc;
           bestm = up ? m[k] : bestm;
         }
@@ -282,24 +324,20 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
   // entries do not), and only the entries whose boxes pass are screened.
   while (local && e < eend)
   {
-    int32_t m[4];
+    const int4 m4 = *reinterpret_cast<const int4*>(la.nbr + e);
+    const int32_t m[4] = { m4.x, m4.y, m4.z, m4.w };
     float lb[4];
+    uint4 wq[4];
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      m[k] = la.nbr[min(e + k, eend - 1)];
+      wq[k] = la.qbox[max(m[k], 0)];
 #pragma unroll
     for (int k = 0; k < 4; k++)
-    {
-      const float* r = leaf_box(m[k]);
-      const float2 b0 = *reinterpret_cast<const float2*>(r);
-      const float2 b1 = *reinterpret_cast<const float2*>(r + 2);
-      const float2 b2 = *reinterpret_cast<const float2*>(r + 4);
-      lb[k] = box_lb(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, xf, yf, zf, eabs);
-    }
+      lb[k] = qbox_lb(wq[k], la.grid, xf, yf, zf, eabs);
     uint32_t pass = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      pass |= (e + k < eend && lb[k] <= boundf) ? (1u << k) : 0u;
+      pass |= (m[k] >= 0 && lb[k] <= boundf) ? (1u << k) : 0u;
     e += 4;
     while (pass)
     {

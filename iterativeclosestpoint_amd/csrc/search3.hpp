@@ -104,6 +104,68 @@ __global__ void k_bin_level(int k, float* __restrict__ nodes)
   }
 }
 
+// Per triangle (Morton position), eight floats: unit normal and the allowance for the
+// stored plane's offset, then centroid and the radius of the circle about it that holds
+// the triangle; for a triangle too thin for its normal to be trusted the normal is zero.
+// From these a query gets a lower bound of its distance to the triangle that, unlike a
+// box's, does not loosen when the triangle is slanted:
+// (distance to the plane)^2 + (in-plane distance to the circle)^2.
+__global__ void k_tri_bounds(const float* __restrict__ tverts, int64_t nt, float4* __restrict__ pre)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nt)
+    return;
+  d3 P0, P1, P2;
+  load_tri(tverts, s, P0, P1, P2);
+  const d3 c = mk((P0.x + P1.x + P2.x) / 3.0, (P0.y + P1.y + P2.y) / 3.0,
+    (P0.z + P1.z + P2.z) / 3.0);
+  const float cx = (float)c.x, cy = (float)c.y, cz = (float)c.z;
+  const d3 cf = mk((double)cx, (double)cy, (double)cz); // the centre as stored
+  const double r2 = fmax(dist2(P0, cf), fmax(dist2(P1, cf), dist2(P2, cf)));
+  const float R = __double2float_ru(sqrt(r2) * (1.0 + 1e-12));
+  const d3 e1 = mk(P1.x - P0.x, P1.y - P0.y, P1.z - P0.z);
+  const d3 e2 = mk(P2.x - P0.x, P2.y - P0.y, P2.z - P0.z);
+  const d3 e3 = mk(P2.x - P1.x, P2.y - P1.y, P2.z - P1.z);
+  const d3 n = mk(e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x);
+  const double len = sqrt(dot3(n, n));
+  const double emax2 = fmax(dot3(e1, e1), fmax(dot3(e2, e2), dot3(e3, e3)));
+  // (a cross product this small against its edges has lost too many digits of direction)
+  const bool ok = len > 1e-6 * emax2;
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  if (ok)
+  {
+    nx = (float)(n.x / len);
+    ny = (float)(n.y / len);
+    nz = (float)(n.z / len);
+  }
+  // the plane the search uses passes through the stored centre; its distance from the
+  // true plane goes into the fourth float as an allowance
+  const double off = ok ? fabs((double)nx * (cf.x - P0.x) + (double)ny * (cf.y - P0.y) +
+                             (double)nz * (cf.z - P0.z)) : 0.0;
+  pre[2 * s] = make_float4(nx, ny, nz, __double2float_ru(off * (1.0 + 1e-6) + 1e-300));
+  pre[2 * s + 1] = make_float4(cx, cy, cz, R);
+}
+
+// fp32 lower bound of the squared distance from (xf,yf,zf) to triangle s; never above
+// the true value.  eabs covers the rounding of coordinates of the scene's magnitude.
+__device__ __forceinline__ float tri_lb(const float4* __restrict__ pre, int64_t s, float xf,
+  float yf, float zf, float eabs)
+{
+  const float4 a = pre[2 * s], b = pre[2 * s + 1];
+  const float vx = xf - b.x, vy = yf - b.y, vz = zf - b.z;
+  const float q2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
+  const float vlen = __builtin_sqrtf(q2);
+  // allowance: coordinates' rounding, the stored plane's offset, the normal's rounding
+  // and the dot product's own rounding (both relative to |v|)
+  const float m = 4.f * eabs + a.w + 6.0e-7f * vlen;
+  const float pd = fabsf(__builtin_fmaf(a.z, vz, __builtin_fmaf(a.y, vy, a.x * vx)));
+  const float pd_lo = fmaxf(pd - m, 0.f), pd_hi = pd + m;
+  const float vlo = fmaxf(vlen * 0.9999995f - 2.f * eabs, 0.f);
+  const float in2 = fmaxf(__builtin_fmaf(vlo, vlo, -(pd_hi * pd_hi)), 0.f);
+  const float ld = fmaxf(__builtin_sqrtf(in2) * 0.9999995f - b.w - 3.f * eabs, 0.f);
+  return __builtin_fmaf(ld, ld, pd_lo * pd_lo) * 0.999999f;
+}
+
 struct Search3Args
 {
   const float* qpos;
@@ -113,6 +175,7 @@ struct Search3Args
   BinTree tree;
   const float* tverts;
   const int32_t* tid;
+  const float4* tpre; // per-triangle plane bounds (k_tri_bounds), used by k_search3q
   int64_t nt;
   int32_t* hint;
   int use_hint;
@@ -623,6 +686,296 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
       }
       need_bt = true;
       atleaf = false;
+    }
+  }
+#ifdef ICPX_STATS
+  atomicAdd(&g_stats[0], st_0);
+  atomicAdd(&g_stats[1], st_1);
+  atomicAdd(&g_stats[2], st_2);
+  atomicAdd(&g_stats[3], st_3);
+  atomicAdd(&g_stats[4], st_4);
+  atomicAdd(&g_stats[5], st_5);
+#endif
+}
+
+// The pooled search with a third kind of step.  A leaf's triangles first meet a cheap fp32
+// lower bound (tri_lb); those that pass are queued per lane (in LDS) instead of being
+// screened on the spot, and the fp64 screen runs as a phase of its own once enough lanes
+// have something queued.  Of the triangles in the leaves a displaced query visits only
+// one in five or so passes the bound, but with 64 lanes in lockstep "some lane passes"
+// is nearly always true, so screening on the spot would run at full cost for a fifth of
+// the lanes.  Same results as k_search3p (a lower bound only removes non-contenders).
+constexpr int PEND3 = 8;
+#ifndef SCREENGO3
+#define SCREENGO3 24
+#endif
+#ifndef LEAFGO3Q
+#define LEAFGO3Q 12
+#endif
+
+template <int L>
+__global__ __launch_bounds__(256) void k_search3q(Search3Args a)
+{
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
+  __shared__ int32_t ring[RING3][256];
+  __shared__ int32_t pend_s[PEND3][256];
+  __shared__ float pend_lb[PEND3][256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int d = a.tree.depth;
+
+  int64_t q = -1;
+  d3 x = mk(0.0, 0.0, 0.0);
+  float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f;
+  double tau = 0.0, best = DBL_MAX, bound = DBL_MAX;
+  float boundf = FLT_MAX;
+  int cnt = 0, npend = 0;
+  int32_t hs_used = -1;
+  uint32_t n = 1, trail = 0;
+  float lbleaf = 0.f;
+  // have: the lane holds a query; walked: its walk is over (queued triangles may remain)
+  bool have = false, walked = false, need_bt = false, atleaf = false;
+  bool dry = false; // the pool has run out (same for every lane of the wavefront)
+  const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
+  if ((int64_t)blockIdx.x * 256 >= total)
+    return; // a short list is served by the first blocks; the rest must not queue at the pool
+#ifdef ICPX_STATS
+  unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0;
+#endif
+
+  auto set_best = [&](double nb) {
+    const double r = sqrt(nb) + tau;
+    const double nbound = r * r;
+    if (nbound < best)
+      cnt = 0; // every older contender was above the old minimum
+    best = nb;
+    bound = nbound;
+    boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
+  };
+
+  while (true)
+  {
+    const bool fin = have && walked && npend == 0;
+    const bool idle = !have || fin;
+    const unsigned long long mi = __ballot(idle);
+    if (__popcll(mi) >= REFILL3 || __ballot(have && !fin) == 0ull)
+    {
+      // results of the finished queries
+      const bool tie = fin && cnt >= 2 && cnt <= RING3;
+      const bool ovf = fin && cnt > RING3;
+      if (fin && !tie && !ovf)
+        a.hint[q] = (cnt == 1) ? ring[0][tid] : -1;
+      const unsigned long long mt = __ballot(tie);
+      if (mt)
+      {
+        const int leader = __ffsll((long long)mt) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&a.counters[0], (uint32_t)__popcll(mt));
+        base = __shfl(base, leader, 64);
+        if (tie)
+        {
+          for (int i = 0; i < RING3; i++)
+            if (i < cnt)
+              a.cand[q * RING3 + i] = ring[i][tid];
+          a.tie_list[base + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
+        }
+      }
+      const unsigned long long mo = __ballot(ovf);
+      if (mo)
+      {
+        const int leader = __ffsll((long long)mo) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&a.counters[1], (uint32_t)__popcll(mo));
+        base = __shfl(base, leader, 64);
+        if (ovf)
+        {
+          a.ovf_best[q] = best;
+          a.ovf_list[base + __popcll(mo & lt)] = (uint32_t)q;
+        }
+      }
+      have = have && !fin;
+
+      // next queries off the pool
+      if (!dry)
+      {
+        const bool want = !have;
+        const unsigned long long mw = __ballot(want);
+        const int leader = __ffsll((long long)mw) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&a.counters[2], (uint32_t)__popcll(mw));
+        base = __shfl(base, leader, 64);
+        const int64_t nq_ = (int64_t)base + __popcll(mw & lt);
+        if (want && nq_ < total)
+        {
+          q = a.qlist ? (int64_t)a.qlist[nq_] : nq_;
+          have = true;
+          walked = false;
+          need_bt = false;
+          atleaf = false;
+          n = 1;
+          trail = 0;
+          cnt = 0;
+          npend = 0;
+          hs_used = -1;
+          best = DBL_MAX;
+          bound = DBL_MAX;
+          boundf = FLT_MAX;
+          x = xform(T, a.qpos + 3 * q);
+          xf = (float)x.x;
+          yf = (float)x.y;
+          zf = (float)x.z;
+          const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
+          eabs = smax * 2.3841858e-07f * 1.0000002f;
+          tau = 1e-9 * (double)smax;
+          int32_t hs = a.use_hint ? a.hint[q] : -1;
+          if (hs < 0 && a.tcodes)
+          {
+            // cold start: the triangle that follows the query along the Morton curve
+            const uint64_t code = morton63(xf, yf, zf, a.box.lo, a.box.inv);
+            int64_t lo = 0, hi = a.nt;
+            while (lo < hi)
+            {
+              const int64_t mid = (lo + hi) >> 1;
+              if (a.tcodes[mid] < code)
+                lo = mid + 1;
+              else
+                hi = mid;
+            }
+            hs = (int32_t)min(lo, a.nt - 1);
+          }
+          if (hs >= 0 && a.tid[hs] >= 0)
+          {
+            d3 P0, P1, P2;
+            load_tri(a.tverts, hs, P0, P1, P2);
+            set_best(tri_d2_screen(x, P0, P1, P2));
+            ring[0][tid] = hs;
+            cnt = 1;
+            hs_used = hs;
+          }
+        }
+        dry = __ballot(want && nq_ >= total) != 0ull;
+      }
+      STAT(5, lane == 0 ? 1 : 0);
+      if (__ballot(have) == 0ull)
+        break;
+    }
+    STAT(4, lane == 0 ? 1 : 0);
+
+    // (1) one step of the walk for every lane that is between leaves (see k_search3)
+    if (have && !walked && !atleaf)
+    {
+      if (need_bt)
+      {
+        if (trail == 0)
+          walked = true;
+        else
+        {
+          const int k = 31 - __clz(trail);
+          trail ^= 1u << k;
+          const int lvl = 31 - __clz(n);
+          n = (n >> (lvl - k - 1)) ^ 1u;
+          need_bt = false;
+          if (k == d - 1)
+          {
+            if (lbleaf > boundf)
+              need_bt = true;
+            else
+              atleaf = true;
+          }
+        }
+      }
+      if (!walked && !need_bt && !atleaf)
+      {
+        STAT(0, 1);
+        const float4* p = reinterpret_cast<const float4*>(a.nodes + (int64_t)n * NODE_FLOATS);
+        const float4 u = p[0], v = p[1], w = p[2];
+        const float lb0 = box_lb(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf, eabs);
+        const float lb1 = box_lb(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf, eabs);
+        const bool ok0 = lb0 <= boundf, ok1 = lb1 <= boundf;
+        if (ok0 || ok1)
+        {
+          const uint32_t near = (ok1 && (!ok0 || lb1 < lb0)) ? 1u : 0u;
+          const int lvl = 31 - __clz(n);
+          if (ok0 && ok1)
+          {
+            trail |= 1u << lvl;
+            lbleaf = (lvl == d - 1) ? (near ? lb0 : lb1) : lbleaf;
+          }
+          n = 2u * n + near;
+          atleaf = (lvl == d - 1);
+        }
+        else
+        {
+          STAT(2, 1);
+          need_bt = true;
+        }
+      }
+    }
+
+    // (2) leaves: the cheap bound on each triangle, once enough lanes stand on a leaf (or
+    // nobody can step); a lane whose queue could overflow waits for a screening phase
+    const bool canstep = have && !walked && !atleaf;
+    const bool canleaf = have && !walked && atleaf && npend <= PEND3 - L;
+    const bool anystep = __ballot(canstep) != 0ull;
+    const int nleaf = __popcll(__ballot(canleaf));
+    bool didleaf = false;
+    if (nleaf >= LEAFGO3Q || (!anystep && nleaf > 0))
+    {
+      didleaf = true;
+      if (canleaf)
+      {
+        STAT(1, 1);
+        const int64_t s0 = (int64_t)(n - (1u << d)) * L;
+#pragma unroll
+        for (int t = 0; t < L; t++)
+        {
+          const int64_t s = s0 + t;
+          if (s < a.nt && a.tid[s] >= 0 && (int32_t)s != hs_used)
+          {
+            const float lb = tri_lb(a.tpre, s, xf, yf, zf, eabs);
+            if (lb <= boundf)
+            {
+              pend_s[npend][tid] = (int32_t)s;
+              pend_lb[npend][tid] = lb;
+              npend++;
+            }
+          }
+        }
+        need_bt = true;
+        atleaf = false;
+      }
+    }
+
+    // (3) screens: the newest queued triangle of every lane that has one, once enough
+    // lanes do (or nothing else could run this trip)
+    const int nscr = __popcll(__ballot(have && npend > 0));
+    if (nscr >= SCREENGO3 || (!anystep && !didleaf && nscr > 0))
+    {
+      if (have && npend > 0)
+      {
+        npend--;
+        const int32_t s = pend_s[npend][tid];
+        if (pend_lb[npend][tid] <= boundf) // (the bound may have tightened since)
+        {
+          STAT(3, 1);
+          d3 P0, P1, P2;
+          load_tri(a.tverts, s, P0, P1, P2);
+          const double d2 = tri_d2_screen(x, P0, P1, P2);
+          if (d2 < best)
+            set_best(d2);
+          if (d2 <= bound)
+          {
+            if (cnt < RING3)
+              ring[cnt][tid] = s;
+            cnt++;
+          }
+        }
+      }
     }
   }
 #ifdef ICPX_STATS

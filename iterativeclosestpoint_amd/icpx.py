@@ -178,7 +178,7 @@ class Context:
         return dict(ties=int(v[0]), overflows=int(v[1]), pool=int(v[2]), fallback=int(v[3]))
 
     def set_persistent(self, enable=True):
-        _chk(load().icpx_set_persistent(self._h, int(bool(enable))))
+        _chk(load().icpx_set_persistent(self._h, int(enable)))
 
     def set_leaf_size(self, triangles):
         _chk(load().icpx_set_leaf_size(self._h, int(triangles)))
