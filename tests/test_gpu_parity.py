@@ -477,6 +477,69 @@ def test_hinted_shortcut_matches_tree_walk(icpx, synth, oracle):
     assert c.debug_stats()["local_passes"] > st["local_passes"]
 
 
+def test_full_size_c3(icpx, synth, oracle):
+    """The benchmark's own workload (1M triangles, 1M points, symmetric metric): rows of a
+    20 000-point sample against the oracle, properties of the whole pass, and the registration."""
+    c = synth.config_c3()
+    ctx = icpx.Context(0)
+    ctx.set_target(c["target_xyz"], c["target_tri"])
+    ctx.set_source(c["source_xyz"], c["source_normals"])
+    rows = ctx.correspond(np.eye(4), step=1, max_dist=10.0, use_source_normals=True)
+    n = len(c["source_xyz"])
+    assert len(rows["cell"]) == n and np.array_equal(rows["src_index"], np.arange(n))
+    pick = (np.arange(20_000) * 49).astype(np.int64)
+    mesh = oracle.Mesh(c["target_xyz"], c["target_tri"])
+    ref = mesh.correspond(c["source_xyz"][pick], step=1, max_dist=10.0,
+                          src_normals=c["source_normals"][pick], grid=True)
+    assert np.array_equal(rows["cell"][pick], ref["cell"])
+    assert np.array_equal(rows["dist"][pick], ref["dist"])
+    assert np.array_equal(rows["closest"][pick], ref["closest"])
+    assert np.abs(rows["normal"][pick] - ref["normal"]).max() <= 1e-6
+    # idempotence: the second pass starts from the first one's winners (shortcut and
+    # surface walk) and must return the same rows
+    again = ctx.correspond(np.eye(4), step=1, max_dist=10.0, use_source_normals=True)
+    for k in ("cell", "dist", "closest", "normal"):
+        assert np.array_equal(rows[k], again[k]), k
+    # every emitted point lies on its triangle's plane to rounding, at the emitted distance
+    P = c["target_xyz"].astype(np.float64)[c["target_tri"][rows["cell"]]]
+    nrm = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    off = np.abs(np.einsum("ij,ij->i", rows["closest"].astype(np.float64) - P[:, 0], nrm))
+    assert off.max() <= 1e-6
+    d = np.linalg.norm(rows["origin"].astype(np.float64) - rows["closest"].astype(np.float64), axis=1)
+    assert np.abs(d - rows["dist"]).max() <= 1e-6
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = 2, 30, n, 10.0
+    T, it, mean, st = ctx.run(p)
+    assert it == 30 and np.abs(T @ c["truth"] - np.eye(4)).max() < 1e-6 and mean < 1e-6
+
+
+def test_large_target_c4_sample(icpx, synth, oracle):
+    """The 10M-triangle target of the large configuration with a 200 000-point noisy scan:
+    tree depth, index widths and the shortcut's policy at scale; 5 000 rows against the oracle."""
+    xyz, tri = synth.bumpy_torus(2500, 2000)
+    pts, f, fn = synth.sample_surface(xyz, tri, 200_000, seed=5)
+    d = synth.diag(xyz)
+    noise = np.stack([synth.gaussian(5, 32 + 2 * k, len(pts)) for k in range(3)], -1) * (1e-3 * d)
+    M = synth.rigid(ry=5.0, t=(0.01 * d / np.sqrt(3),) * 3)
+    src = synth.apply(M, pts.astype(np.float64) + noise)
+    ctx = icpx.Context(0)
+    ctx.set_group_width(1)  # the lane-per-query path, as 16M points would take
+    ctx.set_target(xyz, tri)
+    ctx.set_source(src)
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = 1, 12, len(src), 10.0
+    T, it, mean, st = ctx.run(p)
+    assert it == 12 and np.abs(T @ M - np.eye(4)).max() < 2e-4  # noise floor of 200k samples
+    rows = ctx.correspond(T, step=1, max_dist=10.0)
+    pick = (np.arange(5_000) * 37).astype(np.int64)
+    mesh = oracle.Mesh(xyz, tri)
+    ref = mesh.correspond(src[pick], T=T, step=1, max_dist=10.0, grid=True)
+    for k in ("cell", "dist", "closest"):
+        assert np.array_equal(rows[k][pick], ref[k]), k
+    assert np.abs(rows["normal"][pick] - ref["normal"]).max() <= 1e-6
+
+
 def test_abi_rejects_bad_input(icpx):
     ctx = icpx.Context(0)
     v = np.zeros((3, 3), np.float32)
