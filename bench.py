@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--width", type=int, default=0, help="lanes per query (0 = library default)")
     ap.add_argument("--leaf", type=int, default=0, help="triangles per leaf (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="development: leave out the HIP events around the search kernels")
     args = ap.parse_args()
 
     import torch
@@ -125,7 +127,7 @@ def main():
         torch.cuda.synchronize()
 
     registration(args.warmup)
-    sh.ctx.set_timing(True)
+    sh.ctx.set_timing(not args.no_kernel_timing)
     fence()
     t0 = time.perf_counter()
     T, n_iter, mean_d = registration(args.steps)

@@ -1533,7 +1533,10 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     return rc;
   FinalArgs f;
   fill_final(c, f, max_dist, min_dot, use_sn, use_sn || metric == ICPX_METRIC_PLANE_TO_PLANE);
+  // one resident round: three wavefronts per SIMD (the kernel's register budget) on every CU
   int grid = (int)nblk(c->nq, FIN_THREADS);
+  if (grid > c->num_cus * 3)
+    grid = c->num_cus * 3;
   if (grid > c->max_blocks)
     grid = c->max_blocks;
   {

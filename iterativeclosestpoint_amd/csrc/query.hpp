@@ -362,7 +362,7 @@ __device__ __forceinline__ void add_row(double* acc, const d3& s, const d3& t, c
 constexpr int FIN_THREADS = 256;
 
 template <int METRIC, bool ROWS>
-__global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalArgs a)
+__global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_finalize(FinalArgs a)
 {
   Xf T;
   if (!load_xf(a.T, T))

@@ -77,16 +77,18 @@ class ShardedICP:
         ar = make_allreduce(self.group)
         return sums if ar is None else ar(sums)
 
-    def run_device(self, params):
+    def run_device(self, params, force_collective=False):
         """The whole loop without a host round trip per iteration: search and sums on the
         GPU, all-reduce of the 40 sums on the device (stream-ordered, RCCL), solve and
         transform update on the device.  Needs the device all-reduce buffer (the default).
-        Returns (T 4x4, iterations, mean_distance, status), the same on every rank."""
+        Returns (T 4x4, iterations, mean_distance, status), the same on every rank.
+        force_collective runs the all-reduce even in a one-rank group (a test of the stream
+        ordering between the library's kernels and the collective)."""
         import torch.distributed as dist
 
         assert self.sums_dev is not None, "run_device needs use_device_allreduce=True"
         multi = dist.is_available() and dist.is_initialized() and \
-            dist.get_world_size(self.group) > 1
+            (dist.get_world_size(self.group) > 1 or force_collective)
         ptr = self.sums_dev.data_ptr()
         self.ctx.run_begin(params)
         for _ in range(params.max_iterations):
