@@ -10,7 +10,7 @@
 #include "search2.hpp"
 #include "search3.hpp"
 #include "local.hpp"
-#include "solve_core.hpp"
+#include "state.hpp"
 #include "tables.hpp"
 
 #include <chrono>
@@ -68,23 +68,6 @@ struct Bin
   bool built = false;
 };
 
-// State of a registration that stays on the device between iterations.
-struct RunState
-{
-  double T[16]; // running transform, row-major
-  // ---- the 32 bytes from here on are what the host polls (RunRecord)
-  double mean, n;  // of the last solved iteration
-  int32_t iters;   // solved iterations (vtkICP's NumberOfIterations)
-  int32_t status;  // ICPX_RUN_*
-  int32_t done;    // 1: converged / too few rows; later passes return at once
-  uint32_t fallback; // queries the shortcut left to the tree walk in the last pass
-};
-struct RunRecord
-{
-  double mean, n;
-  int32_t iters, status, done;
-  uint32_t fallback;
-};
 struct Mat16
 {
   double m[16];
@@ -109,56 +92,6 @@ __global__ void k_set_state(RunState* s, Mat16 T, int reset)
   }
 }
 
-// One iteration's solve and transform update in a single GPU thread: the body of the
-// loop in vtkICP::InternalUpdate after the correspondence filter (ICP/vtkICP.cxx:218-245).
-// The iteration's record goes straight to pinned host memory (rec), where the host reads
-// it behind an event two iterations later.
-__device__ void solve_step(RunState* s, const double* __restrict__ sums, int metric,
-  const double* origin, int check_mean, double max_mean)
-{
-  double M[16], n = 0.0, md = 0.0;
-  const int rc = icpx_core::solve_moments(metric, sums, origin, M, &n, &md);
-  s->mean = md;
-  s->n = n;
-  if (check_mean && n > 0.0 && md <= max_mean)
-  {
-    s->status = ICPX_RUN_CONVERGED;
-    s->done = 1;
-    return;
-  }
-  if (rc != ICPX_OK)
-  {
-    s->status = ICPX_RUN_TOO_FEW;
-    s->done = 1;
-    return;
-  }
-  s->iters = s->iters + 1;
-  double R[16];
-  for (int r = 0; r < 4; r++)
-    for (int k = 0; k < 4; k++)
-    {
-      double acc = 0.0;
-      for (int j = 0; j < 4; j++)
-        acc += M[4 * r + j] * s->T[4 * j + k];
-      R[4 * r + k] = acc;
-    }
-  for (int i = 0; i < 16; i++)
-    s->T[i] = R[i];
-}
-
-// {n, sum |s-t|, shortcut fallbacks} of a pass, written to pinned host memory.
-__global__ void k_pass_stat(const double* __restrict__ sums, const uint32_t* __restrict__ counters,
-  double* stat)
-{
-  if (threadIdx.x == 0)
-  {
-    stat[0] = sums[0];
-    stat[1] = sums[1];
-    stat[2] = counters ? (double)counters[7] : 0.0;
-    __threadfence_system();
-  }
-}
-
 __global__ void k_solve(RunState* s, const double* __restrict__ sums, int metric, double ox,
   double oy, double oz, int check_mean, double max_mean, const uint32_t* __restrict__ counters,
   RunRecord* rec)
@@ -171,13 +104,7 @@ __global__ void k_solve(RunState* s, const double* __restrict__ sums, int metric
     s->fallback = counters ? counters[7] : 0u; // snapshot of the pass's fallback count
     solve_step(s, sums, metric, origin, check_mean, max_mean);
   }
-  rec->mean = s->mean;
-  rec->n = s->n;
-  rec->iters = s->iters;
-  rec->status = s->status;
-  rec->done = s->done;
-  rec->fallback = s->fallback;
-  __threadfence_system();
+  publish_record(s, rec);
 }
 
 struct icpx_ctx
@@ -518,6 +445,7 @@ extern "C" int icpx_create(icpx_ctx** out, int device)
     rc = fail(ICPX_E_HIP, "hipEventCreate failed");
   if (!rc)
     rc = dev_alloc(&c->d_state, 1);
+
   if (!rc &&
     (hipHostMalloc((void**)&c->h_rec, sizeof(RunRecord) * 4,
        hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -1533,6 +1461,7 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     return rc;
   FinalArgs f;
   fill_final(c, f, max_dist, min_dot, use_sn, use_sn || metric == ICPX_METRIC_PLANE_TO_PLANE);
+  const bool want_stat = stat && !c->stat_pending; // (what the shortcut's policy looks at)
   // one resident round: three wavefronts per SIMD (the kernel's register budget) on every CU
   int grid = (int)nblk(c->nq, FIN_THREADS);
   if (grid > c->num_cus * 3)
@@ -1548,16 +1477,13 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     else
       k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
   }
-  k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(
-    c->d_partials, grid, dst, &c->d_state->done, c->d_counters);
+  k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, &c->d_state->done,
+    c->d_counters, want_stat ? c->d_stat : nullptr);
   LAUNCHCHK();
   if (c->d_counters)
     c->counters_clean = true;
-  if (stat && !c->stat_pending)
+  if (want_stat)
   {
-    // what the shortcut's policy looks at, whenever it has arrived
-    k_pass_stat<<<1, 64, 0, st>>>(dst, c->d_counters, c->d_stat);
-    LAUNCHCHK();
     HIPCHK(hipEventRecord(c->ev_stat, st));
     c->stat_pending = true;
   }

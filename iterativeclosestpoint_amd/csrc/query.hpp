@@ -277,6 +277,7 @@ struct FinalArgs
   uint32_t* o_flag;
   // partial sums, [gridDim.x][ICPX_NSUMS] (sums only)
   double* partials;
+ // pinned {n, sum |s-t|, shortcut fallbacks} for the host's policy, or null
 };
 
 template <int METRIC>
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))
 // depends only on the number of blocks, so results repeat run to run.
 __global__ __launch_bounds__(64) void k_reduce_partials(
   const double* __restrict__ partials, int nblocks, double* __restrict__ sums,
-  const int32_t* __restrict__ stop, uint32_t* __restrict__ counters)
+  const int32_t* __restrict__ stop, uint32_t* __restrict__ counters, double* __restrict__ stat)
 {
   if (stop && *stop)
     return; // the pass did not run
@@ -497,9 +498,14 @@ __global__ __launch_bounds__(64) void k_reduce_partials(
   {
     // the search kernels' four pass counters move up for whoever wants to look at them,
     // and are left at zero for the next pass
-    counters[4 + l] = counters[l];
+    const uint32_t old = counters[l];
+    counters[4 + l] = old;
     counters[l] = 0u;
+    if (stat && l == 3)
+      stat[2] = (double)old; // shortcut fallbacks of this pass
   }
+  if (stat && !counters && i == 0 && l == 0)
+    stat[2] = 0.0;
   double v = 0.0;
   for (int b = l; b < nblocks; b += 64)
     v += partials[(int64_t)b * ICPX_NSUMS + i];
@@ -507,7 +513,15 @@ __global__ __launch_bounds__(64) void k_reduce_partials(
   for (int m = 32; m >= 1; m >>= 1)
     v += __shfl_xor(v, m, 64);
   if (l == 0)
+  {
     sums[i] = v;
+    // {n, sum |s-t|} (and, above, the shortcut's fallbacks) for the host's policy, in
+    // pinned memory
+    if (stat && i < 2)
+      stat[i] = v;
+    if (stat)
+      __threadfence_system();
+  }
 }
 
 // Query set-up: gather the kept points (and normals) of the shard into Morton order.

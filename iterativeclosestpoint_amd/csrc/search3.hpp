@@ -203,6 +203,26 @@ __device__ __forceinline__ float box_lb(float lox, float loy, float loz, float h
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * 0.99999952f;
 }
 
+// The tree walk's box test without the per-axis allowance: the raw fp32 squared distance
+// to the box, to be compared with a bound that carries the allowance instead.  If each
+// axis distance is off by at most eabs, the raw distance exceeds the true one by at most
+// sqrt(3)*eabs, so a box whose true distance is within sqrt(bound) has a raw squared
+// distance within box_bound(bound, eabs).
+__device__ __forceinline__ float box_d2(float lox, float loy, float loz, float hix, float hiy,
+  float hiz, float xf, float yf, float zf)
+{
+  const float dx = fmaxf(fmaxf(lox - xf, xf - hix), 0.f);
+  const float dy = fmaxf(fmaxf(loy - yf, yf - hiy), 0.f);
+  const float dz = fmaxf(fmaxf(loz - zf, zf - hiz), 0.f);
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+__device__ __forceinline__ float box_bound(float boundf, float eabs)
+{
+  // (every rounding below is covered by the two factors)
+  const float r = __builtin_sqrtf(boundf) * 1.0000005f + 1.7320509f * eabs;
+  return r * r * 1.000002f;
+}
+
 template <int L, bool EXACT>
 __global__ __launch_bounds__(256) void k_search3(Search3Args a)
 {
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(256) void k_search3(Search3Args a)
   d3 x = mk(0.0, 0.0, 0.0);
   float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f;
   double tau = 0.0, best = DBL_MAX, bound = DBL_MAX;
-  float boundf = FLT_MAX;
+  float boundf = FLT_MAX, bboxf = INFINITY; // bound for triangles / for raw box distances
   int cnt = 0;
   int32_t hs_used = -1;  // the hinted triangle already sits in the ring
   double ed2 = INFINITY; // EXACT mode: exact minimum so far
@@ -241,6 +261,7 @@ __global__ __launch_bounds__(256) void k_search3(Search3Args a)
     best = nb;
     bound = nbound;
     boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
+    bboxf = box_bound(boundf, eabs);
   };
 
   if (active)
@@ -311,7 +332,7 @@ __global__ __launch_bounds__(256) void k_search3(Search3Args a)
           need_bt = false;
           if (k == d - 1)
           {
-            if (lbleaf > boundf)
+            if (lbleaf > bboxf)
               need_bt = true; // went stale meanwhile
             else
               atleaf = true;
@@ -322,9 +343,9 @@ __global__ __launch_bounds__(256) void k_search3(Search3Args a)
       {
         const float4* p = reinterpret_cast<const float4*>(a.nodes + (int64_t)n * NODE_FLOATS);
         const float4 u = p[0], v = p[1], w = p[2];
-        const float lb0 = box_lb(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf, eabs);
-        const float lb1 = box_lb(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf, eabs);
-        const bool ok0 = lb0 <= boundf, ok1 = lb1 <= boundf;
+        const float lb0 = box_d2(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf);
+        const float lb1 = box_d2(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf);
+        const bool ok0 = lb0 <= bboxf, ok1 = lb1 <= bboxf;
         if (ok0 || ok1)
         {
           const uint32_t near = (ok1 && (!ok0 || lb1 < lb0)) ? 1u : 0u;
@@ -470,7 +491,7 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
   d3 x = mk(0.0, 0.0, 0.0);
   float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f;
   double tau = 0.0, best = DBL_MAX, bound = DBL_MAX;
-  float boundf = FLT_MAX;
+  float boundf = FLT_MAX, bboxf = INFINITY; // bound for triangles / for raw box distances
   int cnt = 0;
   int32_t hs_used = -1;
   uint32_t n = 1, trail = 0;
@@ -492,6 +513,7 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
     best = nb;
     bound = nbound;
     boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
+    bboxf = box_bound(boundf, eabs);
   };
 
   while (true)
@@ -563,6 +585,7 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
           best = DBL_MAX;
           bound = DBL_MAX;
           boundf = FLT_MAX;
+          bboxf = INFINITY;
           x = xform(T, a.qpos + 3 * q);
           xf = (float)x.x;
           yf = (float)x.y;
@@ -620,7 +643,7 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
           need_bt = false;
           if (k == d - 1)
           {
-            if (lbleaf > boundf)
+            if (lbleaf > bboxf)
               need_bt = true;
             else
               atleaf = true;
@@ -632,9 +655,9 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
         STAT(0, 1);
         const float4* p = reinterpret_cast<const float4*>(a.nodes + (int64_t)n * NODE_FLOATS);
         const float4 u = p[0], v = p[1], w = p[2];
-        const float lb0 = box_lb(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf, eabs);
-        const float lb1 = box_lb(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf, eabs);
-        const bool ok0 = lb0 <= boundf, ok1 = lb1 <= boundf;
+        const float lb0 = box_d2(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf);
+        const float lb1 = box_d2(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf);
+        const bool ok0 = lb0 <= bboxf, ok1 = lb1 <= bboxf;
         if (ok0 || ok1)
         {
           const uint32_t near = (ok1 && (!ok0 || lb1 < lb0)) ? 1u : 0u;
@@ -730,7 +753,7 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
   d3 x = mk(0.0, 0.0, 0.0);
   float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f;
   double tau = 0.0, best = DBL_MAX, bound = DBL_MAX;
-  float boundf = FLT_MAX;
+  float boundf = FLT_MAX, bboxf = INFINITY; // bound for triangles / for raw box distances
   int cnt = 0, npend = 0;
   int32_t hs_used = -1;
   uint32_t n = 1, trail = 0;
@@ -753,6 +776,7 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
     best = nb;
     bound = nbound;
     boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
+    bboxf = box_bound(boundf, eabs);
   };
 
   while (true)
@@ -825,6 +849,7 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
           best = DBL_MAX;
           bound = DBL_MAX;
           boundf = FLT_MAX;
+          bboxf = INFINITY;
           x = xform(T, a.qpos + 3 * q);
           xf = (float)x.x;
           yf = (float)x.y;
@@ -882,7 +907,7 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
           need_bt = false;
           if (k == d - 1)
           {
-            if (lbleaf > boundf)
+            if (lbleaf > bboxf)
               need_bt = true;
             else
               atleaf = true;
@@ -894,9 +919,9 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
         STAT(0, 1);
         const float4* p = reinterpret_cast<const float4*>(a.nodes + (int64_t)n * NODE_FLOATS);
         const float4 u = p[0], v = p[1], w = p[2];
-        const float lb0 = box_lb(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf, eabs);
-        const float lb1 = box_lb(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf, eabs);
-        const bool ok0 = lb0 <= boundf, ok1 = lb1 <= boundf;
+        const float lb0 = box_d2(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf);
+        const float lb1 = box_d2(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf);
+        const bool ok0 = lb0 <= bboxf, ok1 = lb1 <= bboxf;
         if (ok0 || ok1)
         {
           const uint32_t near = (ok1 && (!ok0 || lb1 < lb0)) ? 1u : 0u;
