@@ -323,6 +323,54 @@ def test_vtkicp_surface(icpx, synth, small):
     assert np.array_equal(bad.GetMatrix(), np.eye(4))
 
 
+def test_filter_surface(icpx, synth, oracle):
+    """vtkPolyDataCorrespondenceFilter mirror: two outputs, stride rule, threshold, origin
+    normals with MinNormalDot, transform, and the reversed search direction."""
+    from iterativeclosestpoint_amd import vtkPolyData, vtkPolyDataCorrespondenceFilter as F
+    xyz, tri = synth.bumpy_torus(96, 48)
+    T = synth.rigid(ry=4.0, t=(0.02, 0.0, -0.01))
+    moved = synth.apply(T, xyz)
+    mesh_t = oracle.Mesh(xyz, tri)
+    f = F.New()
+    f.SetInputData(0, vtkPolyData(moved, tri))
+    f.SetInputData(1, vtkPolyData(xyz, tri))
+    f.SetMaximumNumberOfLandmarks(1000)                        # step = 4608 // 1000 = 4
+    f.SetMaximumDistance(0.05)
+    f.Update()
+    ref = mesh_t.correspond(moved, step=len(moved) // 1000, max_dist=0.05, grid=True)
+    assert 0 < len(ref["cell"]) < len(moved[::4])              # the threshold rejects some
+    assert np.array_equal(f.GetOutput(0).GetPoints(), ref["origin"])
+    assert np.array_equal(f.GetOutput(1).GetPoints(), ref["closest"])
+    assert np.abs(f.GetOutput(1).GetPointNormals() - ref["normal"]).max() <= 1e-6
+    assert f.GetOutput(0).GetPointNormals() is None
+    assert np.array_equal(f.Cells, ref["cell"]) and np.array_equal(f.SourceIndices, ref["src_index"])
+    # with the inverse transform and origin normals; a MinNormalDot that rejects some rows
+    Tinv = np.linalg.inv(T)
+    f.SetTransform(Tinv)
+    f.IncludeOriginNormalsOn()
+    f.SetMinNormalDot(0.9999)
+    f.SetMaximumNumberOfLandmarks(10 ** 9)
+    f.Update()
+    from iterativeclosestpoint_amd.vtkicp import point_normals_like_vtkPolyDataNormals
+    sn = point_normals_like_vtkPolyDataNormals(moved, tri)
+    ref = mesh_t.correspond(moved, T=Tinv, step=1, max_dist=0.05, src_normals=sn, min_dot=0.9999,
+                            grid=True)
+    assert 0 < len(ref["cell"]) < len(moved)                   # the normals are not rotated (Q7)
+    assert np.array_equal(f.GetOutput(0).GetPoints(), ref["origin"])
+    assert np.array_equal(f.GetOutput(0).GetPointNormals(), ref["origin_normal"])
+    assert np.array_equal(f.GetOutput(1).GetPoints(), ref["closest"])
+    # reversed direction: port 1's points are searched against port 0's mesh
+    g = F.New()
+    g.SetInputData(0, vtkPolyData(moved, tri))
+    g.SetInputData(1, vtkPolyData(xyz, tri))
+    g.SetTargetToSource()
+    g.Update()
+    ref = oracle.Mesh(moved, tri).correspond(xyz, step=1, max_dist=10.0, grid=True)
+    assert np.array_equal(g.GetOutput(0).GetPoints(), ref["origin"])
+    assert np.array_equal(g.GetOutput(1).GetPoints(), ref["closest"])
+    assert np.array_equal(g.Cells, ref["cell"])
+
+
 def test_golden_fixtures(icpx, synth):
     """The committed oracle outputs (tests/golden) reproduced on the GPU."""
     import os

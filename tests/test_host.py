@@ -191,3 +191,39 @@ def test_vtkicp_defaults_and_errors(capsys):
     other = icp.MakeTransform()
     other.DeepCopy(icp)
     assert other.GetMetric() == icp.GetMetric() and other.GetSource() is icp.GetSource()
+
+
+def test_filter_defaults_and_failures(capsys):
+    """vtkPolyDataCorrespondenceFilter mirror: constructor defaults
+    (vtkPolyDataCorrespondenceFilter.cxx:349-366) and the early returns of RequestData
+    (:407-455), none of which reach the GPU."""
+    from iterativeclosestpoint_amd import vtkPolyDataCorrespondenceFilter as F
+    f = F.New()
+    assert f.GetMaximumDistance() == 10.0 and f.GetMaximumNumberOfLandmarks() == 2147483647
+    assert f.GetOutputPrecision() == F.DEFAULT_PRECISION and f.GetMinNormalDot() == 0.0
+    assert f.GetSearchDirection() == F.SourceToTarget and f.GetIncludeOriginNormals() is False
+    assert np.array_equal(f.GetTransform(), np.eye(4))
+    assert f.GetNumberOfInputPorts() == 2 and f.GetNumberOfOutputPorts() == 2
+    f.SetSearchDirection(9)
+    assert f.GetSearchDirection() == F.TargetToSource          # vtkSetClampMacro
+    f.SetSourceToTarget()
+    assert f.RequestData() == 0                                # no inputs
+    xyz, tri = synth.bumpy_torus(8, 4)
+    f.SetInputData(0, vtkPolyData(xyz, tri))
+    assert f.RequestData() == 0                                # one input
+    f.SetInputData(1, vtkPolyData(xyz.astype(np.float64), tri))
+    assert f.RequestData() == 0 and "same type" in capsys.readouterr().err
+    f.SetInputData(0, vtkPolyData(xyz.astype(np.float64), tri))
+    assert f.RequestData() == 0 and "only support float" in capsys.readouterr().err
+    f.SetInputData(0, vtkPolyData(xyz, tri))
+    f.SetInputData(1, vtkPolyData(xyz, tri))
+    f.SetOutputPrecision(F.DOUBLE_PRECISION)
+    assert f.RequestData() == 0 and "Double output" in capsys.readouterr().err
+    f.SetOutputPrecision(F.SINGLE_PRECISION)
+    f.SetInputData(1, vtkPolyData(xyz))                        # a target without polygons
+    assert f.RequestData() == 0 and "No polygons" in capsys.readouterr().err
+    f.SetInputData(1, vtkPolyData(xyz, tri))
+    f.SetInputData(0, vtkPolyData(xyz))                        # a cloud: no faces, no normals
+    f.IncludeOriginNormalsOn()
+    assert f.RequestData() == 0 and "vertex normals" in capsys.readouterr().err
+    assert f.GetOutput(0).GetNumberOfPoints() == 0 and f.GetOutput(1).GetNumberOfPoints() == 0
