@@ -183,8 +183,8 @@ def main():
                 "bound": "hbm",
                 "kernel": "k_search",
                 "kernel_note": "one launch = the search kernels of one pass on the library's "
-                               "stream (k_search_local + k_search3p + k_resolve_ties + "
-                               "k_search3<.,true>), HIP events around them",
+                               "stream (k_search_local + k_search3p + k_contested), HIP events "
+                               "around them",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -1101,8 +1101,7 @@ static void launch_search3(
   unsigned rgrid = grid / 8 + 1;
   if (rgrid > 2048)
     rgrid = 2048;
-  k_resolve_ties<<<rgrid, 256, 0, st>>>(a);
-  k_search3<L, true><<<grid, 256, 0, st>>>(a);
+  k_contested<L><<<rgrid + grid, 256, 0, st>>>(a, rgrid);
 }
 
 // Neighbour lists of every leaf of the one-triangle-per-leaf tree for radius eps (see

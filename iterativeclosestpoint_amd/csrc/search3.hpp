@@ -14,7 +14,7 @@
 // routine of tri.hpp only for near-ties (within 1e-9 x the largest coordinate
 // of the minimum).  A query whose minimum is not contested is finished by this
 // kernel; contested ones (2..8 contenders) are listed and settled by
-// k_resolve_ties, eight lanes per query, one contender per lane; the rare query
+// k_contested (resolve_ties_body), eight lanes per query, one contender per lane; the rare query
 // with more contenders than the ring holds is re-run by k_search3 in its
 // EXACT mode, which knows the final bound and evaluates every contender
 // exactly as it meets it.
@@ -224,14 +224,14 @@ __device__ __forceinline__ float box_bound(float boundf, float eabs)
 }
 
 template <int L, bool EXACT>
-__global__ __launch_bounds__(256) void k_search3(Search3Args a)
+__device__ __forceinline__ void search3_body(const Search3Args& a, unsigned block)
 {
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
   __shared__ int32_t ring[RING3][256];
   const int tid = threadIdx.x;
-  int64_t q = (int64_t)blockIdx.x * 256 + tid;
+  int64_t q = (int64_t)block * 256 + tid;
   bool active;
   if (EXACT)
   {
@@ -452,6 +452,12 @@ __global__ __launch_bounds__(256) void k_search3(Search3Args a)
       a.ovf_list[base + __popcll(mo & lt)] = (uint32_t)q;
     }
   }
+}
+
+template <int L, bool EXACT>
+__global__ __launch_bounds__(256) void k_search3(Search3Args a)
+{
+  search3_body<L, EXACT>(a, blockIdx.x);
 }
 
 // The same search with lanes that outlive their queries.  A fixed grid of wavefronts
@@ -1015,15 +1021,16 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
 
 // Contested queries: eight lanes per query, one contender per lane, exact
 // evaluation, (dist2, cell id) minimum by DPP exchanges.
-__global__ __launch_bounds__(256) void k_resolve_ties(Search3Args a)
+__device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned block,
+  unsigned nblocks)
 {
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
   const uint32_t total = a.counters[0];
   const int j = threadIdx.x & 7;
-  const uint32_t ngroups = gridDim.x * 32u;
-  for (uint32_t r = blockIdx.x * 32u + (threadIdx.x >> 3); r < total; r += ngroups)
+  const uint32_t ngroups = nblocks * 32u;
+  for (uint32_t r = block * 32u + (threadIdx.x >> 3); r < total; r += ngroups)
   {
     const uint2 rec = a.tie_list[r];
     const int64_t q = rec.x;
@@ -1046,6 +1053,17 @@ __global__ __launch_bounds__(256) void k_resolve_ties(Search3Args a)
     if (j == 0)
       a.hint[q] = s;
   }
+}
+
+// Both kinds of contested query in one launch: the first `rblocks` blocks resolve the near
+// ties, the rest walk the tree again for the queries whose contenders overflowed the ring.
+template <int L>
+__global__ __launch_bounds__(256) void k_contested(Search3Args a, unsigned rblocks)
+{
+  if (blockIdx.x < rblocks)
+    resolve_ties_body(a, blockIdx.x, rblocks);
+  else
+    search3_body<L, true>(a, blockIdx.x - rblocks);
 }
 
 } // namespace icpx

@@ -243,14 +243,14 @@ ICPX_HD inline void solve6(const double Ain[6][6], const double bin[6], double x
     for (int i = k + 1; i < 6; i++)
       col[i] = A[i][k];
     for (int i = k + 1; i < 6; i++)
+    {
+      const double li = col[i] / d; // one division per row
       for (int j = k + 1; j <= i; j++)
       {
-        A[i][j] -= col[i] / d * col[j];
+        A[i][j] -= li * col[j];
         A[j][i] = A[i][j];
       }
-    for (int i = k + 1; i < 6; i++)
-    {
-      A[i][k] = col[i] / d;
+      A[i][k] = li;
       A[k][i] = 0.0;
     }
   }
@@ -387,13 +387,13 @@ ICPX_HD inline int solve_moments(int metric, const double* sums, const double* o
       at.v[i] /= an;
   const M3 W = skew(at);
   const M3 W2 = mul(W, W);
+  const double st = sin(theta), ct = cos(theta);
   M3 Ri;
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++)
-      Ri.v[i][j] = (i == j ? 1.0 : 0.0) + sin(theta) * W.v[i][j] +
-        (1.0 - cos(theta)) * W2.v[i][j];
+      Ri.v[i][j] = (i == j ? 1.0 : 0.0) + st * W.v[i][j] + (1.0 - ct) * W2.v[i][j];
   const M3 R = mul(Ri, Ri);
-  V3 t2 = { { cos(theta) * x[3], cos(theta) * x[4], cos(theta) * x[5] } };
+  V3 t2 = { { ct * x[3], ct * x[4], ct * x[5] } };
   const V3 Rp = mulv(R, pm), Rt = mulv(Ri, t2);
   V3 t = { { -Rp.v[0] + Rt.v[0] + qm.v[0], -Rp.v[1] + Rt.v[1] + qm.v[1],
     -Rp.v[2] + Rt.v[2] + qm.v[2] } };

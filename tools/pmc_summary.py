@@ -9,7 +9,7 @@ table = OrderedDict()
 for f in sorted(glob.glob(out + "/*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_search" not in k and "k_resolve" not in k and "k_finalize" not in k:
+        if "k_search" not in k and "k_contested" not in k and "k_finalize" not in k:
             continue
         key = (int(r["Dispatch_Id"]), k.split("(")[0][-40:])
         table.setdefault(key, {})[r["Counter_Name"]] = float(r["Counter_Value"])

@@ -11,7 +11,7 @@ import csv
 import json
 import sys
 
-SEARCH = ("k_search", "k_resolve_ties")
+SEARCH = ("k_search", "k_contested")
 
 
 def per_pass(path, counter):
