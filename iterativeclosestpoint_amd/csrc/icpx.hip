@@ -1139,12 +1139,14 @@ static int build_nbr(icpx_ctx* c, const Bin& b, float eps)
   ALLOC(c->d_nbr, (int64_t)total + 4);
   k_nbr<true><<<nblk(nl, 256), 256, 0, st>>>(b.nodes, b.t, eps2, nullptr, c->d_noff, c->d_nbr);
   ALLOC(c->d_qbox, nl);
+  float ext = 0.f;
   for (int a = 0; a < 3; a++)
   {
-    const float ext = c->box.inv[a] > 0.f ? 1.f / c->box.inv[a] : 0.f;
+    ext = std::fmax(ext, c->box.inv[a] > 0.f ? 1.f / c->box.inv[a] : 0.f);
     c->qgrid.base[a] = c->box.lo[a];
-    c->qgrid.step[a] = std::fmax(ext * 1.000001f, 1e-30f) / 65535.f;
   }
+  c->qgrid.step = std::fmax(ext * 1.000001f, 1e-30f) / 65535.f;
+  c->qgrid.inv_step = 1.f / c->qgrid.step;
   k_quant_boxes<<<nblk(nl, 256), 256, 0, st>>>(b.nodes, b.t, c->qgrid, c->d_qbox);
   LAUNCHCHK();
   c->nbr_eps = eps;

@@ -107,12 +107,16 @@ __global__ __launch_bounds__(256) void k_nbr(const float* __restrict__ nodes, Bi
       nbr[base + j] = -1;
 }
 
-// Leaf boxes on a 16-bit grid over the target's bounds, rounded outwards by one extra
-// step, six values packed into one 16-byte record: the search reads a neighbour's box
-// with a single load.  A box test on the looser box can only admit more triangles.
+// Leaf boxes on a 16-bit grid over the target's bounds (one step for all three axes),
+// rounded outwards by one extra step, six values packed into one 16-byte record: the
+// search reads a neighbour's box with a single load and tests it in grid units, where a
+// query is converted once.  The extra step covers that conversion and the coordinates'
+// own rounding, so a grid-space distance never exceeds the true one divided by the step;
+// a box test on the looser box can only admit more triangles.
 struct QuantGrid
 {
-  float base[3], step[3];
+  float base[3];
+  float step, inv_step;
 };
 
 __global__ void k_quant_boxes(const float* __restrict__ nodes, BinTree t, QuantGrid g,
@@ -127,25 +131,21 @@ __global__ void k_quant_boxes(const float* __restrict__ nodes, BinTree t, QuantG
 #pragma unroll
   for (int a = 0; a < 3; a++)
   {
-    const double lo = floor(((double)r[a] - (double)g.base[a]) / (double)g.step[a]) - 1.0;
-    const double hi = ceil(((double)r[3 + a] - (double)g.base[a]) / (double)g.step[a]) + 1.0;
+    const double lo = floor(((double)r[a] - (double)g.base[a]) / (double)g.step) - 1.0;
+    const double hi = ceil(((double)r[3 + a] - (double)g.base[a]) / (double)g.step) + 1.0;
     q[a] = (uint32_t)fmin(fmax(lo, 0.0), 65535.0);
     q[3 + a] = (uint32_t)fmin(fmax(hi, 0.0), 65535.0);
   }
   out[i] = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), 0u);
 }
 
-// lower bound of the squared distance from the query to a quantised leaf box
-__device__ __forceinline__ float qbox_lb(const uint4 w, const QuantGrid& g, float xf, float yf,
-  float zf, float eabs)
+// squared distance, in grid steps, from the query (in grid coordinates) to a quantised box
+__device__ __forceinline__ float qbox_g2(const uint4 w, float gx, float gy, float gz)
 {
-  const float lox = __builtin_fmaf((float)(w.x & 0xffffu), g.step[0], g.base[0]);
-  const float loy = __builtin_fmaf((float)(w.x >> 16), g.step[1], g.base[1]);
-  const float loz = __builtin_fmaf((float)(w.y & 0xffffu), g.step[2], g.base[2]);
-  const float hix = __builtin_fmaf((float)(w.y >> 16), g.step[0], g.base[0]);
-  const float hiy = __builtin_fmaf((float)(w.z & 0xffffu), g.step[1], g.base[1]);
-  const float hiz = __builtin_fmaf((float)(w.z >> 16), g.step[2], g.base[2]);
-  return box_lb(lox, loy, loz, hix, hiy, hiz, xf, yf, zf, eabs);
+  const float dx = fmaxf(fmaxf((float)(w.x & 0xffffu) - gx, gx - (float)(w.y >> 16)), 0.f);
+  const float dy = fmaxf(fmaxf((float)(w.x >> 16) - gy, gy - (float)(w.z & 0xffffu)), 0.f);
+  const float dz = fmaxf(fmaxf((float)(w.y & 0xffffu) - gz, gz - (float)(w.z >> 16)), 0.f);
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
 struct LocalArgs
@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
   d3 x = mk(0.0, 0.0, 0.0);
   float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f;
   double tau = 0.0, best = DBL_MAX, bound = DBL_MAX;
-  float boundf = FLT_MAX;
+  float boundf = FLT_MAX, boundg = INFINITY; // bound for triangles / in grid steps for boxes
+  float gx = 0.f, gy = 0.f, gz = 0.f;        // the query in grid coordinates
+  const float ginv2 = la.grid.inv_step * la.grid.inv_step * 1.00001f;
   int cnt = 0;
   int32_t hs = -1;
   bool local = false;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
     best = nb;
     bound = nbound;
     boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
+    boundg = boundf * ginv2;
   };
 
   uint32_t e = 0, eend = 0;
@@ -228,11 +231,12 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
     }
     // a triangle can settle the query only if the query is within eps/2 of it; its box
     // gives a cheap lower bound of that distance
+    gx = (xf - la.grid.base[0]) * la.grid.inv_step;
+    gy = (yf - la.grid.base[1]) * la.grid.inv_step;
+    gz = (zf - la.grid.base[2]) * la.grid.inv_step;
     const float half = 0.5f * la.eps;
-    const float reach2 = half * half;
-    const float gsx = la.grid.step[0], gsy = la.grid.step[1], gsz = la.grid.step[2];
-    const float qx2 = 2.f * (xf - la.grid.base[0]), qy2 = 2.f * (yf - la.grid.base[1]),
-                qz2 = 2.f * (zf - la.grid.base[2]);
+    const float reach_g = half * half * ginv2;
+    const float qx2 = 2.f * gx, qy2 = 2.f * gy, qz2 = 2.f * gz;
     bool moving = hs >= 0;
     for (int step = 0; moving; step++)
     {
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
       eend = la.noff[hs + 1];
       if (eend - e > NBR_CAP)
         break; // its list was cut short: nothing can be concluded here
-      if (qbox_lb(wb, la.grid, xf, yf, zf, eabs) <= reach2 && a.tid[hs] >= 0)
+      if (qbox_g2(wb, gx, gy, gz) <= reach_g && a.tid[hs] >= 0)
       {
         d3 P0, P1, P2;
         load_tri(a.tverts, hs, P0, P1, P2);
@@ -273,9 +277,9 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
         for (int k = 0; k < 4; k++)
         {
           // twice the box centre, in grid steps, against twice the query
-          const float cx = ((float)(wq[k].x & 0xffffu) + (float)(wq[k].y >> 16)) * gsx - qx2;
-          const float cy = ((float)(wq[k].x >> 16) + (float)(wq[k].z & 0xffffu)) * gsy - qy2;
-          const float cz = ((float)(wq[k].y & 0xffffu) + (float)(wq[k].z >> 16)) * gsz - qz2;
+          const float cx = ((float)(wq[k].x & 0xffffu) + (float)(wq[k].y >> 16)) - qx2;
+          const float cy = ((float)(wq[k].x >> 16) + (float)(wq[k].z & 0xffffu)) - qy2;
+          const float cz = ((float)(wq[k].y & 0xffffu) + (float)(wq[k].z >> 16)) - qz2;
           const float dc = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx));
           // (strict, and ties to the lower position, so the walk cannot cycle)
           const bool up = m[k] >= 0 && (dc < bestc || (dc == bestc && m[k] < bestm));
@@ -333,11 +337,11 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
       wq[k] = la.qbox[max(m[k], 0)];
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      lb[k] = qbox_lb(wq[k], la.grid, xf, yf, zf, eabs);
+      lb[k] = qbox_g2(wq[k], gx, gy, gz);
     uint32_t pass = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      pass |= (m[k] >= 0 && lb[k] <= boundf) ? (1u << k) : 0u;
+      pass |= (m[k] >= 0 && lb[k] <= boundg) ? (1u << k) : 0u;
     e += 4;
     while (pass)
     {
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
       pass &= pass - 1;
       const int32_t s = (k == 0) ? m[0] : (k == 1) ? m[1] : (k == 2) ? m[2] : m[3];
       const float lbk = (k == 0) ? lb[0] : (k == 1) ? lb[1] : (k == 2) ? lb[2] : lb[3];
-      if (lbk > boundf || s == hs || a.tid[s] < 0)
+      if (lbk > boundg || s == hs || a.tid[s] < 0)
         continue; // the bound tightened since the test / the centre itself / degenerate
       d3 P0, P1, P2;
       load_tri(a.tverts, s, P0, P1, P2);
