@@ -627,6 +627,59 @@ def test_device_loop_with_rccl_collective(icpx, synth, small):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_shortcut_on_triangle_soup(icpx, synth, oracle, seed):
+    """Hinted passes (neighbour lists, surface walk, fallback, ties) on a mesh that is nothing
+    like a smooth manifold: overlapping random triangles of very different sizes, slivers,
+    duplicates and a flat fan, with queries on, near and far from it, under a drifting
+    transform.  Every pass's rows equal the oracle's."""
+    n = 6000
+    c = (np.stack([synth.u01(seed, 10 + k, n) for k in range(3)], -1) - 0.5) * 2.0
+    size = 0.002 + 0.2 * synth.u01(seed, 20, n) ** 4                 # sizes over two decades
+    e1 = (np.stack([synth.u01(seed, 30 + k, n) for k in range(3)], -1) - 0.5) * size[:, None]
+    e2 = (np.stack([synth.u01(seed, 40 + k, n) for k in range(3)], -1) - 0.5) * size[:, None]
+    sliver = synth.u01(seed, 50, n) < 0.1
+    e2[sliver] = e1[sliver] * 0.5 + e2[sliver] * 1e-4                # slivers
+    P = np.stack([c, c + e1, c + e2], 1)
+    fan_c = np.array([0.1, 0.2, 0.3])
+    ang = np.linspace(0, 2 * np.pi, 25)
+    fan = np.stack([np.repeat(fan_c[None], 24, 0),
+                    fan_c + 0.05 * np.stack([np.cos(ang[:-1]), np.sin(ang[:-1]), 0 * ang[:-1]], -1),
+                    fan_c + 0.05 * np.stack([np.cos(ang[1:]), np.sin(ang[1:]), 0 * ang[1:]], -1)], 1)
+    P = np.concatenate([P, fan, P[:200]], 0)                         # and 200 duplicates
+    xyz = np.ascontiguousarray(P.reshape(-1, 3), np.float32)
+    tri = np.arange(len(xyz), dtype=np.int32).reshape(-1, 3)
+    mesh = oracle.Mesh(xyz, tri)
+    nq = 20000
+    t = (synth.u01(seed, 60, nq) * len(tri)).astype(np.int64) % len(tri)
+    w = np.stack([synth.u01(seed, 61 + k, nq) for k in range(3)], -1) + 1e-3
+    w /= w.sum(1, keepdims=True)
+    on = np.einsum("ij,ijk->ik", w, xyz[tri[t]].astype(np.float64))
+    off = np.stack([synth.gaussian(seed, 70 + 2 * k, nq) for k in range(3)], -1)
+    scale = np.where(synth.u01(seed, 80, nq) < 0.5, 0.0, 10.0 ** (-6 + 5 * synth.u01(seed, 81, nq)))
+    q = on + off * scale[:, None]
+    q[:50] = fan_c + np.array([0, 0, 1.0]) * np.linspace(1e-6, 0.2, 50)[:, None]  # above the fan
+    q = q.astype(np.float32)
+    ctxs = []
+    for local in (True, False):
+        c_ = icpx.Context(0)
+        c_.set_group_width(1)
+        c_.set_local(local)
+        c_.set_target(xyz, tri)
+        c_.set_source(q)
+        ctxs.append(c_)
+    Ts = [np.eye(4), np.eye(4), synth.rigid(rz=0.02, t=(1e-4, 0, 0)), synth.rigid(rz=0.02, t=(1e-4, 0, 0)),
+          synth.rigid(rx=0.5, t=(0.003, -0.002, 0.001)), np.eye(4), np.eye(4)]
+    for i, T in enumerate(Ts):
+        ref = mesh.correspond(q, T=T, step=1, max_dist=10.0, grid=True)
+        for c_ in ctxs:
+            if i in (1, 5):
+                c_.set_local(c_ is ctxs[0])  # (restarts the shortcut's policy after far passes)
+            check_rows(c_.correspond(T, step=1, max_dist=10.0), ref)
+            c_.accumulate(1, T, step=1, max_dist=10.0)  # a second hinted pass at the same pose
+    assert ctxs[0].debug_stats()["local_passes"] >= 6
+
+
 def test_abi_rejects_bad_input(icpx):
     ctx = icpx.Context(0)
     v = np.zeros((3, 3), np.float32)
