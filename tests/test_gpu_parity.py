@@ -680,6 +680,69 @@ def test_shortcut_on_triangle_soup(icpx, synth, oracle, seed):
     assert ctxs[0].debug_stats()["local_passes"] >= 6
 
 
+def _sharded_rank(rank, world, port, metric, out):
+    """One rank of test_sharded_device_loop_two_ranks (spawned)."""
+    import torch.distributed as dist
+    from iterativeclosestpoint_amd import icpx as ix, synth as sy
+    from iterativeclosestpoint_amd.distributed import ShardedICP
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    xyz, tri = sy.bumpy_torus(200, 100)
+    pts, f, fn = sy.sample_surface(xyz, tri, 50_001, seed=9)      # an odd count: uneven shards
+    M = sy.rigid(ry=3.0, t=(0.01, 0.0, 0.02))
+    src = sy.apply(M, pts)
+    sn = (fn.astype(np.float64) @ M[:3, :3].T).astype(np.float32)
+    sh = ShardedICP(device=0, rank=rank, world=world)
+    sh.set_target(xyz, tri)
+    sh.set_source(src, sn)
+    p = ix.default_params()
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = metric, 12, len(src), 10.0
+    p.check_mean_distance, p.max_mean_distance = 1, 1e-7
+    T, it, mean, st = sh.run_device(p)
+    out.put((rank, T, it, mean, st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric", (1, 2))
+def test_sharded_device_loop_two_ranks(icpx, synth, metric):
+    """The multi-GPU driver's loop with two ranks (two processes sharing this GPU, gloo
+    carrying the device tensors): each searches its shard, the 40 sums are all-reduced on the
+    stream, both solve on the device; same transform and stop as one rank with everything."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_rank, args=(r, 2, port, metric, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    xyz, tri = synth.bumpy_torus(200, 100)
+    pts, f, fn = synth.sample_surface(xyz, tri, 50_001, seed=9)
+    M = synth.rigid(ry=3.0, t=(0.01, 0.0, 0.02))
+    src = synth.apply(M, pts)
+    sn = (fn.astype(np.float64) @ M[:3, :3].T).astype(np.float32)
+    one = icpx.Context(0)
+    one.set_target(xyz, tri)
+    one.set_source(src, sn)
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = metric, 12, len(src), 10.0
+    p.check_mean_distance, p.max_mean_distance = 1, 1e-7
+    T, it, mean, st = one.run(p)
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:]
+    assert (res[0][2], res[0][4]) == (it, st)
+    assert rel_err(res[0][1], T) <= 1e-11 and abs(res[0][3] - mean) <= 1e-12
+    assert np.abs(T @ M - np.eye(4)).max() < 1e-5
+
+
 def test_abi_rejects_bad_input(icpx):
     ctx = icpx.Context(0)
     v = np.zeros((3, 3), np.float32)
