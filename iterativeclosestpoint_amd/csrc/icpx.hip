@@ -138,6 +138,7 @@ struct icpx_ctx
   uint32_t* d_noff = nullptr;
   int32_t* d_nbr = nullptr;
   uint4* d_qbox = nullptr; // quantised leaf boxes of the one-triangle-per-leaf tree
+  float4* d_edges = nullptr; // edge half-spaces of the triangles
   QuantGrid qgrid;
   uint32_t* d_fallback = nullptr;
   double* h_stat = nullptr; // pinned {n, sum |s-t|, shortcut fallbacks} of a finished pass
@@ -351,6 +352,7 @@ static void free_target(icpx_ctx* c)
   dev_free(&c->d_noff);
   dev_free(&c->d_nbr);
   dev_free(&c->d_qbox);
+  dev_free(&c->d_edges);
   c->nbr_eps = 0.f;
   c->nbr_state = 0;
   c->stat_valid = false;
@@ -1148,6 +1150,8 @@ static int build_nbr(icpx_ctx* c, const Bin& b, float eps)
   c->qgrid.step = std::fmax(ext * 1.000001f, 1e-30f) / 65535.f;
   c->qgrid.inv_step = 1.f / c->qgrid.step;
   k_quant_boxes<<<nblk(nl, 256), 256, 0, st>>>(b.nodes, b.t, c->qgrid, c->d_qbox);
+  ALLOC(c->d_edges, 3 * c->nt);
+  k_tri_edges<<<nblk(c->nt, 256), 256, 0, st>>>(c->d_tverts, c->nt, c->d_edges);
   LAUNCHCHK();
   c->nbr_eps = eps;
   return ICPX_OK;
@@ -1277,6 +1281,7 @@ static int run_search3(icpx_ctx* c)
     la.noff = c->d_noff;
     la.nbr = c->d_nbr;
     la.qbox = c->d_qbox;
+    la.edges = c->d_edges;
     la.grid = c->qgrid;
     la.eps = c->nbr_eps;
     la.fallback = c->d_fallback;

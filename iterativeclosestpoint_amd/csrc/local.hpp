@@ -148,6 +148,65 @@ __device__ __forceinline__ float qbox_g2(const uint4 w, float gx, float gy, floa
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
+// Per triangle (Morton position), three records {m.xyz, d}: the half-spaces m.y <= d that
+// contain the triangle and are bounded by the planes through its edges perpendicular to
+// it (m is the unit in-plane normal of the edge, pointing away from the third vertex).  A
+// query outside one of them by delta is at least delta from the triangle: for a query on a
+// smooth surface that rules out, with three dot products, the neighbours whose boxes it
+// sits in but whose edges it is outside of.  A triangle too thin for its normal to be
+// trusted, or an edge too short, gets a zero record (never rules anything out).
+__global__ void k_tri_edges(const float* __restrict__ tverts, int64_t nt, float4* __restrict__ edges)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nt)
+    return;
+  d3 P[3];
+  load_tri(tverts, s, P[0], P[1], P[2]);
+  const d3 e1 = mk(P[1].x - P[0].x, P[1].y - P[0].y, P[1].z - P[0].z);
+  const d3 e2 = mk(P[2].x - P[0].x, P[2].y - P[0].y, P[2].z - P[0].z);
+  const d3 e3 = mk(P[2].x - P[1].x, P[2].y - P[1].y, P[2].z - P[1].z);
+  const d3 n = mk(e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x);
+  const double nlen = sqrt(dot3(n, n));
+  const double emax2 = fmax(dot3(e1, e1), fmax(dot3(e2, e2), dot3(e3, e3)));
+  const bool flat_ok = nlen > 1e-6 * emax2;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+  {
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    const d3 e = mk(P[j].x - P[i].x, P[j].y - P[i].y, P[j].z - P[i].z);
+    d3 m = mk(e.y * n.z - e.z * n.y, e.z * n.x - e.x * n.z, e.x * n.y - e.y * n.x);
+    const d3 toK = mk(P[k].x - P[i].x, P[k].y - P[i].y, P[k].z - P[i].z);
+    if (dot3(m, toK) > 0.0)
+      m = mk(-m.x, -m.y, -m.z);
+    const double mlen = sqrt(dot3(m, m));
+    float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (flat_ok && mlen > 1e-6 * nlen * sqrt(emax2) && mlen > 0.0)
+    {
+      const float mx = (float)(m.x / mlen), my = (float)(m.y / mlen), mz = (float)(m.z / mlen);
+      // d for the normal as stored, at the edge's farther end (the half-space must hold
+      // the whole triangle even after the normal's rounding)
+      const double di = (double)mx * P[i].x + (double)my * P[i].y + (double)mz * P[i].z;
+      const double dj = (double)mx * P[j].x + (double)my * P[j].y + (double)mz * P[j].z;
+      const double dk = (double)mx * P[k].x + (double)my * P[k].y + (double)mz * P[k].z;
+      rec = make_float4(mx, my, mz, __double2float_ru(fmax(fmax(di, dj), dk)));
+    }
+    edges[3 * s + i] = rec;
+  }
+}
+
+// How far (at least) the query is outside one of the triangle's edge half-spaces; <= 0
+// when it is outside none.  alw covers every rounding of the evaluation.
+__device__ __forceinline__ float edge_excess(const float4* __restrict__ edges, int32_t s,
+  float xf, float yf, float zf, float alw)
+{
+  const float4 a = edges[3 * (int64_t)s], b = edges[3 * (int64_t)s + 1],
+               c = edges[3 * (int64_t)s + 2];
+  const float da = __builtin_fmaf(a.z, zf, __builtin_fmaf(a.y, yf, a.x * xf)) - a.w;
+  const float db = __builtin_fmaf(b.z, zf, __builtin_fmaf(b.y, yf, b.x * xf)) - b.w;
+  const float dc = __builtin_fmaf(c.z, zf, __builtin_fmaf(c.y, yf, c.x * xf)) - c.w;
+  return fmaxf(fmaxf(da, db), dc) - alw;
+}
+
 struct LocalArgs
 {
   Search3Args s;        // the tree kernel's arguments (queries, tree, triangles, tie lists);
@@ -155,12 +214,14 @@ struct LocalArgs
   const uint32_t* noff; // neighbour lists, CSR over triangles (Morton positions); every
   const int32_t* nbr;   // list starts on a multiple of four entries and is padded with -1
   const uint4* qbox;    // quantised leaf boxes
+  const float4* edges;  // edge half-spaces (k_tri_edges)
   QuantGrid grid;
   float eps;            // radius the lists were built for
   uint32_t* fallback;   // queries left to the tree kernel; their count is counters[3]
 };
 
 constexpr int LOCAL_STEPS = 16; // moves along the surface before a query is given up
+constexpr int LOCAL_PEND = 6;   // triangles a lane may hold for the screening loop
 
 // One lane per query.  Start: last pass's winner, or (no winner) the triangle next to the
 // query on the Morton curve.  While the start triangle is too far for its list to hold
@@ -176,6 +237,7 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
   __shared__ int32_t ring[RING3][256];
+  __shared__ int32_t pendq[LOCAL_PEND][256];
   __shared__ uint32_t wcount[4];
   __shared__ uint32_t bbase;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -325,45 +387,50 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
 
   // The list is taken four entries at a time: four indices, then four boxes, are in
   // flight together (the loads of one entry depend on each other, those of different
-  // entries do not), and only the entries whose boxes pass are screened.
+  // entries do not).  Entries whose boxes pass meet the edge half-spaces; the few that
+  // survive are held back and screened after the scan, so that the fp64 screen runs once
+  // or twice per wavefront instead of once per "some lane's box passed".
+  const float alw = 6.f * eabs;
+  int npend = 0;
+  auto screen = [&](int32_t s) {
+    d3 P0, P1, P2;
+    load_tri(a.tverts, s, P0, P1, P2);
+    const double d2 = tri_d2_screen(x, P0, P1, P2);
+    if (d2 < best)
+      set_best(d2);
+    if (d2 <= bound)
+    {
+      if (cnt < RING3)
+        ring[cnt][tid] = s;
+      cnt++;
+    }
+  };
   while (local && e < eend)
   {
     const int4 m4 = *reinterpret_cast<const int4*>(la.nbr + e);
     const int32_t m[4] = { m4.x, m4.y, m4.z, m4.w };
-    float lb[4];
     uint4 wq[4];
 #pragma unroll
     for (int k = 0; k < 4; k++)
       wq[k] = la.qbox[max(m[k], 0)];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      lb[k] = qbox_g2(wq[k], gx, gy, gz);
-    uint32_t pass = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      pass |= (m[k] >= 0 && lb[k] <= boundg) ? (1u << k) : 0u;
     e += 4;
-    while (pass)
+#pragma unroll
+    for (int k = 0; k < 4; k++)
     {
-      const int k = __ffs((int)pass) - 1;
-      pass &= pass - 1;
-      const int32_t s = (k == 0) ? m[0] : (k == 1) ? m[1] : (k == 2) ? m[2] : m[3];
-      const float lbk = (k == 0) ? lb[0] : (k == 1) ? lb[1] : (k == 2) ? lb[2] : lb[3];
-      if (lbk > boundg || s == hs || a.tid[s] < 0)
-        continue; // the bound tightened since the test / the centre itself / degenerate
-      d3 P0, P1, P2;
-      load_tri(a.tverts, s, P0, P1, P2);
-      const double d2 = tri_d2_screen(x, P0, P1, P2);
-      if (d2 < best)
-        set_best(d2);
-      if (d2 <= bound)
-      {
-        if (cnt < RING3)
-          ring[cnt][tid] = s;
-        cnt++;
-      }
+      const int32_t s = m[k];
+      if (s < 0 || s == hs || qbox_g2(wq[k], gx, gy, gz) > boundg)
+        continue;
+      const float ex = edge_excess(la.edges, s, xf, yf, zf, alw);
+      if ((ex > 0.f && ex * ex * 0.999999f > boundf) || a.tid[s] < 0)
+        continue; // outside an edge by more than the bound / degenerate
+      if (npend < LOCAL_PEND)
+        pendq[npend++][tid] = s;
+      else
+        screen(s);
     }
   }
+  for (int i = 0; i < npend; i++)
+    screen(pendq[i][tid]);
 
   // settle (as the tree kernel does)
   const bool tie = local && cnt >= 2 && cnt <= RING3;
