@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
     }
   }
 
-  // The list is taken four entries at a time: four indices, then four boxes, are in
+  // The list is taken eight entries at a time: the indices, then their boxes, are in
   // flight together (the loads of one entry depend on each other, those of different
   // entries do not).  Entries whose boxes pass meet the edge half-spaces; the few that
   // survive are held back and screened after the scan, so that the fp64 screen runs once
@@ -407,15 +407,19 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
   };
   while (local && e < eend)
   {
-    const int4 m4 = *reinterpret_cast<const int4*>(la.nbr + e);
-    const int32_t m[4] = { m4.x, m4.y, m4.z, m4.w };
-    uint4 wq[4];
+    // eight entries (two aligned groups) per round
+    const int4 ma = *reinterpret_cast<const int4*>(la.nbr + e);
+    int4 mb = make_int4(-1, -1, -1, -1);
+    if (e + 4 < eend)
+      mb = *reinterpret_cast<const int4*>(la.nbr + e + 4);
+    const int32_t m[8] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w };
+    uint4 wq[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 8; k++)
       wq[k] = la.qbox[max(m[k], 0)];
-    e += 4;
+    e += 8;
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 8; k++)
     {
       const int32_t s = m[k];
       if (s < 0 || s == hs || qbox_g2(wq[k], gx, gy, gz) > boundg)
