@@ -132,6 +132,7 @@ struct icpx_ctx
   // hinted shortcut: per-leaf neighbour lists for one radius, and the residual statistics
   // of the previous pass that choose the radius
   int use_local = 1;
+  int refill_override = 0; // development: pooled kernels' refill threshold (0 = by regime)
   int nbr_state = 0;    // 0 not tried, 1 built, -1 not worth it for this mesh
   float nbr_eps = 0.f;  // radius the lists cover
   float mesh_edge = 0.f; // typical edge length of the target (sampled)
@@ -640,6 +641,11 @@ extern "C" int icpx_set_local(icpx_ctx* c, int enable)
 
 extern "C" int icpx_set_persistent(icpx_ctx* c, int enable)
 {
+  if (c && enable >= 100)
+  {
+    c->refill_override = enable - 100; // development: 100+n sets the refill threshold to n
+    return ICPX_OK;
+  }
   if (!c)
     return fail(ICPX_E_INVALID, "null context");
   c->persistent = enable < 0 ? 0 : enable > 2 ? 2 : enable;
@@ -1262,6 +1268,7 @@ static int run_search3(icpx_ctx* c)
   a.ovf_list = c->d_ovf_list;
   a.ovf_best = c->d_ovf_best;
   a.qlist = nullptr;
+  a.refill = c->refill_override > 0 ? c->refill_override : (c->hint_valid ? 40 : REFILL3);
   hipStream_t st = c->stream;
   const unsigned grid = nblk(c->nq, 256);
   bool use_local = false;

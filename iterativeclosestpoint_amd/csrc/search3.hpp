@@ -189,6 +189,7 @@ struct Search3Args
   uint32_t* ovf_list;   // queries with more contenders than the ring holds
   double* ovf_best;     // their screened minimum, indexed by query
   const uint32_t* qlist; // persistent kernel: serve only these queries (count in counters[3]), or null
+  int refill;            // pooled kernels: idle lanes of a wavefront that trigger taking new queries
 };
 
 constexpr int RING3 = 8;
@@ -461,9 +462,9 @@ __global__ __launch_bounds__(256) void k_search3(Search3Args a)
 }
 
 // The same search with lanes that outlive their queries.  A fixed grid of wavefronts
-// draws queries from a shared counter: whenever a quarter of a wavefront's lanes
-// have finished (or all of them), the finished ones write their results and take
-// the next queries off the pool.  Query costs differ widely (a point ten triangle
+// draws queries from a shared counter: whenever most of a wavefront's lanes (REFILL3 of
+// 64; taking queries is itself a costly step, so it is done for many lanes at once) have
+// finished, the finished ones write their results and take the next queries off the pool.  Query costs differ widely (a point ten triangle
 // widths off the surface meets a hundred boxes, a point on it a dozen), and with
 // one query per lane for the lifetime of a wavefront most lanes sit idle waiting
 // for the slowest; refilling keeps them busy.  Results are per query and do not
@@ -477,7 +478,9 @@ __device__ unsigned long long g_stats[8];
 #define STAT(i, v)
 #endif
 
-constexpr int REFILL3 = 16;
+#ifndef REFILL3
+#define REFILL3 56
+#endif
 #ifndef LEAFGO3
 #define LEAFGO3 24
 #endif
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
   {
     const bool idle = !have || fin;
     const unsigned long long mi = __ballot(idle);
-    if (__popcll(mi) >= REFILL3 || __ballot(have && !fin) == 0ull)
+    if (__popcll(mi) >= a.refill || __ballot(have && !fin) == 0ull)
     {
       // results of the finished queries
       const bool f = have && fin;
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
     const bool fin = have && walked && npend == 0;
     const bool idle = !have || fin;
     const unsigned long long mi = __ballot(idle);
-    if (__popcll(mi) >= REFILL3 || __ballot(have && !fin) == 0ull)
+    if (__popcll(mi) >= a.refill || __ballot(have && !fin) == 0ull)
     {
       // results of the finished queries
       const bool tie = fin && cnt >= 2 && cnt <= RING3;

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--leaf", type=int, default=0)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--refill", type=int, default=0)
     a = ap.parse_args()
     c = {"c3": synth.config_c3, "c4": synth.config_c4}[a.workload]()
     metric = c["metric"]
@@ -24,6 +25,8 @@ def main():
         ctx.set_group_width(a.width)
     if a.leaf:
         ctx.set_leaf_size(a.leaf)
+    if a.refill:
+        ctx.set_persistent(100 + a.refill)
     ctx.set_target(c["target_xyz"], c["target_tri"])
     ctx.set_source(c["source_xyz"], c["source_normals"])
     for rep in range(2):
