@@ -22,6 +22,13 @@
 #else
 #define ICPX_HD
 #endif
+// Work arrays that are indexed by run-time values (pivoting) would live in scratch memory
+// on the device; the device runs this code in a single thread, so they go to LDS there.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ICPX_WS __shared__
+#else
+#define ICPX_WS
+#endif
 
 namespace icpx_core
 {
@@ -209,8 +216,10 @@ ICPX_HD inline M3 kabsch_rotation(const M3& S)
 // that component at zero (the behaviour of Eigen::LDLT::solve the reference relies on).
 ICPX_HD inline void solve6(const double Ain[6][6], const double bin[6], double x[6])
 {
-  double A[6][6], y[6];
-  int perm[6];
+  ICPX_WS double A[6][6];
+  ICPX_WS double y[6];
+  ICPX_WS double col[6];
+  ICPX_WS int perm[6];
   for (int i = 0; i < 6; i++)
     for (int j = 0; j < 6; j++)
       A[i][j] = Ain[i][j];
@@ -239,7 +248,6 @@ ICPX_HD inline void solve6(const double Ain[6][6], const double bin[6], double x
         A[i][k] = A[k][i] = 0.0;
       continue;
     }
-    double col[6];
     for (int i = k + 1; i < 6; i++)
       col[i] = A[i][k];
     for (int i = k + 1; i < 6; i++)
