@@ -212,8 +212,14 @@ extern "C"
 
   /* Lane-per-query kernel scheduling: 1 (default) = a resident grid whose lanes draw
    * queries from a pool as they finish; 0 = one query per lane for the lifetime of a
-   * wavefront.  Same results. */
+   * wavefront; 2 = the pooled kernel with a per-triangle plane bound and queued screens
+   * (experimental, slower today).  Same results. */
   int icpx_set_persistent(icpx_ctx* ctx, int enable);
+
+  /* Pooled kernels: how many of a wavefront's 64 lanes must be idle before it takes new
+   * queries off the pool.  0 (default) = by regime (56 on a cold pass, 40 on a hinted one).
+   * Same results. */
+  int icpx_set_refill(icpx_ctx* ctx, int lanes);
 
   /* Search kernel selection.  0 (default): the production kernel, which screens
    * triangles with a short fp64 routine and evaluates only near-ties (within

@@ -132,7 +132,7 @@ struct icpx_ctx
   // hinted shortcut: per-leaf neighbour lists for one radius, and the residual statistics
   // of the previous pass that choose the radius
   int use_local = 1;
-  int refill_override = 0; // development: pooled kernels' refill threshold (0 = by regime)
+  int refill_override = 0; // pooled kernels' refill threshold (0 = by regime)
   int nbr_state = 0;    // 0 not tried, 1 built, -1 not worth it for this mesh
   float nbr_eps = 0.f;  // radius the lists cover
   float mesh_edge = 0.f; // typical edge length of the target (sampled)
@@ -639,13 +639,19 @@ extern "C" int icpx_set_local(icpx_ctx* c, int enable)
   return ICPX_OK;
 }
 
+extern "C" int icpx_set_refill(icpx_ctx* c, int lanes)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  if (lanes < 0 || lanes > 64)
+    return fail(ICPX_E_INVALID, "refill threshold must be 0 (by regime) or 1..64 lanes (got %d)", lanes);
+  c->refill_override = lanes;
+  return ICPX_OK;
+}
+
 extern "C" int icpx_set_persistent(icpx_ctx* c, int enable)
 {
-  if (c && enable >= 100)
-  {
-    c->refill_override = enable - 100; // development: 100+n sets the refill threshold to n
-    return ICPX_OK;
-  }
+
   if (!c)
     return fail(ICPX_E_INVALID, "null context");
   c->persistent = enable < 0 ? 0 : enable > 2 ? 2 : enable;

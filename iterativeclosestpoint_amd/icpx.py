@@ -26,7 +26,7 @@ SYMBOLS = (
     "icpx_set_allreduce", "icpx_run", "icpx_last_build_seconds", "icpx_set_group_width",
     "icpx_reset_hints", "icpx_set_timing", "icpx_get_timing", "icpx_set_exhaustive",
     "icpx_set_leaf_size", "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local",
-    "icpx_run_begin", "icpx_run_enqueue", "icpx_run_update", "icpx_run_end",
+    "icpx_run_begin", "icpx_run_enqueue", "icpx_run_update", "icpx_run_end", "icpx_set_refill",
 )
 
 
@@ -88,6 +88,7 @@ def load():
     lib.icpx_set_exhaustive.argtypes = [vp, ci]
     lib.icpx_set_leaf_size.argtypes = [vp, ci]
     lib.icpx_set_persistent.argtypes = [vp, ci]
+    lib.icpx_set_refill.argtypes = [vp, ci]
     lib.icpx_set_local.argtypes = [vp, ci]
     lib.icpx_debug_dump.argtypes = [vp, ci, vp, i64]
     lib.icpx_set_timing.argtypes = [vp, ci]
@@ -179,6 +180,9 @@ class Context:
 
     def set_persistent(self, enable=True):
         _chk(load().icpx_set_persistent(self._h, int(enable)))
+
+    def set_refill(self, lanes):
+        _chk(load().icpx_set_refill(self._h, int(lanes)))
 
     def set_leaf_size(self, triangles):
         _chk(load().icpx_set_leaf_size(self._h, int(triangles)))

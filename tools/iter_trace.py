@@ -26,7 +26,7 @@ def main():
     if a.leaf:
         ctx.set_leaf_size(a.leaf)
     if a.refill:
-        ctx.set_persistent(100 + a.refill)
+        ctx.set_refill(a.refill)
     ctx.set_target(c["target_xyz"], c["target_tri"])
     ctx.set_source(c["source_xyz"], c["source_normals"])
     for rep in range(2):
