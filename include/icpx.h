@@ -212,8 +212,9 @@ extern "C"
 
   /* Lane-per-query kernel scheduling: 1 (default) = a resident grid whose lanes draw
    * queries from a pool as they finish; 0 = one query per lane for the lifetime of a
-   * wavefront; 2 = the pooled kernel with a per-triangle plane bound and queued screens
-   * (experimental, slower today).  Same results. */
+   * wavefront; 2 = the pooled kernel with cheap per-triangle lower and upper bounds and
+   * fp64 screens deferred to the end of each walk (ten times fewer screens; faster on
+   * hinted displaced passes, slower on cold ones today).  Same results. */
   int icpx_set_persistent(icpx_ctx* ctx, int enable);
 
   /* Pooled kernels: how many of a wavefront's 64 lanes must be idle before it takes new

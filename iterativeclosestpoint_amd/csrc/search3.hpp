@@ -146,26 +146,6 @@ __global__ void k_tri_bounds(const float* __restrict__ tverts, int64_t nt, float
   pre[2 * s + 1] = make_float4(cx, cy, cz, R);
 }
 
-// fp32 lower bound of the squared distance from (xf,yf,zf) to triangle s; never above
-// the true value.  eabs covers the rounding of coordinates of the scene's magnitude.
-__device__ __forceinline__ float tri_lb(const float4* __restrict__ pre, int64_t s, float xf,
-  float yf, float zf, float eabs)
-{
-  const float4 a = pre[2 * s], b = pre[2 * s + 1];
-  const float vx = xf - b.x, vy = yf - b.y, vz = zf - b.z;
-  const float q2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
-  const float vlen = __builtin_sqrtf(q2);
-  // allowance: coordinates' rounding, the stored plane's offset, the normal's rounding
-  // and the dot product's own rounding (both relative to |v|)
-  const float m = 4.f * eabs + a.w + 6.0e-7f * vlen;
-  const float pd = fabsf(__builtin_fmaf(a.z, vz, __builtin_fmaf(a.y, vy, a.x * vx)));
-  const float pd_lo = fmaxf(pd - m, 0.f), pd_hi = pd + m;
-  const float vlo = fmaxf(vlen * 0.9999995f - 2.f * eabs, 0.f);
-  const float in2 = fmaxf(__builtin_fmaf(vlo, vlo, -(pd_hi * pd_hi)), 0.f);
-  const float ld = fmaxf(__builtin_sqrtf(in2) * 0.9999995f - b.w - 3.f * eabs, 0.f);
-  return __builtin_fmaf(ld, ld, pd_lo * pd_lo) * 0.999999f;
-}
-
 struct Search3Args
 {
   const float* qpos;
@@ -175,7 +155,7 @@ struct Search3Args
   BinTree tree;
   const float* tverts;
   const int32_t* tid;
-  const float4* tpre; // per-triangle plane bounds (k_tri_bounds), used by k_search3q
+  const float4* tpre; // per-triangle bounds records (k_tri_bounds), used by k_search3q
   int64_t nt;
   int32_t* hint;
   int use_hint;
@@ -730,20 +710,40 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
 #endif
 }
 
-// The pooled search with a third kind of step.  A leaf's triangles first meet a cheap fp32
-// lower bound (tri_lb); those that pass are queued per lane (in LDS) instead of being
-// screened on the spot, and the fp64 screen runs as a phase of its own once enough lanes
-// have something queued.  Of the triangles in the leaves a displaced query visits only
-// one in five or so passes the bound, but with 64 lanes in lockstep "some lane passes"
-// is nearly always true, so screening on the spot would run at full cost for a fifth of
-// the lanes.  Same results as k_search3p (a lower bound only removes non-contenders).
+// The pooled search with cheap bounds on both sides.  At a leaf every triangle yields, from
+// its eight-float record (tri_bounds), a lower bound of its distance to the query (plane
+// distance and in-plane distance to the circumscribing circle) and an upper bound (the
+// distance to its centroid).  The smallest upper bound seen tightens the pruning of boxes
+// and triangles just as an fp64 screen would; a triangle whose lower bound is within it
+// is only queued (per lane, in LDS).  The queue is screened in fp64 when the walk is over,
+// by then against the final bound, so a displaced query that meets 160 triangles screens
+// a handful, and it does so together with the other lanes that finished: the screen runs at
+// high lane utilisation instead of once per "some lane's triangle passed".  Same results
+// as k_search3p: bounds only ever remove triangles that cannot be contenders.
 constexpr int PEND3 = 8;
-#ifndef SCREENGO3
-#define SCREENGO3 24
-#endif
 #ifndef LEAFGO3Q
-#define LEAFGO3Q 12
+#define LEAFGO3Q 16
 #endif
+
+// lower and upper fp32 bounds of the squared distance from the query to triangle s
+__device__ __forceinline__ void tri_bounds(const float4* __restrict__ pre, int64_t s, float xf,
+  float yf, float zf, float eabs, float& lb, float& ub)
+{
+  const float4 a = pre[2 * s], b = pre[2 * s + 1];
+  const float vx = xf - b.x, vy = yf - b.y, vz = zf - b.z;
+  const float q2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
+  const float vlen = __builtin_sqrtf(q2);
+  const float m = 4.f * eabs + a.w + 6.0e-7f * vlen;
+  const float pd = fabsf(__builtin_fmaf(a.z, vz, __builtin_fmaf(a.y, vy, a.x * vx)));
+  const float pd_lo = fmaxf(pd - m, 0.f), pd_hi = pd + m;
+  const float vlo = fmaxf(vlen * 0.9999995f - 2.f * eabs, 0.f);
+  const float in2 = fmaxf(__builtin_fmaf(vlo, vlo, -(pd_hi * pd_hi)), 0.f);
+  const float ld = fmaxf(__builtin_sqrtf(in2) * 0.9999995f - b.w - 3.f * eabs, 0.f);
+  lb = __builtin_fmaf(ld, ld, pd_lo * pd_lo) * 0.999999f;
+  // the stored centroid is within a rounding of a point of the triangle
+  const float vhi = vlen * 1.000001f + 2.f * eabs;
+  ub = vhi * vhi * 1.000001f;
+}
 
 template <int L>
 __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
@@ -760,9 +760,12 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
 
   int64_t q = -1;
   d3 x = mk(0.0, 0.0, 0.0);
-  float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f;
+  float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f, tauf = 0.f;
   double tau = 0.0, best = DBL_MAX, bound = DBL_MAX;
-  float boundf = FLT_MAX, bboxf = INFINITY; // bound for triangles / for raw box distances
+  // boundf: from fp64 screens; ubf: smallest cheap upper bound; prunef: what triangles are
+  // tested against (the smaller of the two, the second widened by the tie tolerance);
+  // bboxf: the same for raw box distances
+  float boundf = FLT_MAX, ubf = FLT_MAX, prunef = FLT_MAX, bboxf = INFINITY;
   int cnt = 0, npend = 0;
   int32_t hs_used = -1;
   uint32_t n = 1, trail = 0;
@@ -777,6 +780,11 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
   unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0;
 #endif
 
+  auto retighten = [&]() {
+    const float r = __builtin_sqrtf(ubf) * 1.000001f + tauf;
+    prunef = fminf(boundf, r * r * 1.000001f);
+    bboxf = box_bound(prunef, eabs);
+  };
   auto set_best = [&](double nb) {
     const double r = sqrt(nb) + tau;
     const double nbound = r * r;
@@ -785,17 +793,40 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
     best = nb;
     bound = nbound;
     boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
-    bboxf = box_bound(boundf, eabs);
+    retighten();
+  };
+  auto screen_one = [&]() { // the newest queued triangle, if it is still in the race
+    npend--;
+    const int32_t s = pend_s[npend][tid];
+    if (pend_lb[npend][tid] <= prunef)
+    {
+      STAT(3, 1);
+      d3 P0, P1, P2;
+      load_tri(a.tverts, s, P0, P1, P2);
+      const double d2 = tri_d2_screen(x, P0, P1, P2);
+      if (d2 < best)
+        set_best(d2);
+      if (d2 <= bound)
+      {
+        if (cnt < RING3)
+          ring[cnt][tid] = s;
+        cnt++;
+      }
+    }
   };
 
   while (true)
   {
-    const bool fin = have && walked && npend == 0;
-    const bool idle = !have || fin;
+    const bool idle = !have || walked;
     const unsigned long long mi = __ballot(idle);
-    if (__popcll(mi) >= a.refill || __ballot(have && !fin) == 0ull)
+    if (__popcll(mi) >= a.refill || __ballot(have && !walked) == 0ull)
     {
+      // the lanes whose walks are over screen what they queued, together
+      while (__ballot(have && walked && npend > 0) != 0ull)
+        if (have && walked && npend > 0)
+          screen_one();
       // results of the finished queries
+      const bool fin = have && walked;
       const bool tie = fin && cnt >= 2 && cnt <= RING3;
       const bool ovf = fin && cnt > RING3;
       if (fin && !tie && !ovf)
@@ -858,6 +889,8 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
           best = DBL_MAX;
           bound = DBL_MAX;
           boundf = FLT_MAX;
+          ubf = FLT_MAX;
+          prunef = FLT_MAX;
           bboxf = INFINITY;
           x = xform(T, a.qpos + 3 * q);
           xf = (float)x.x;
@@ -866,6 +899,7 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
           const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
           eabs = smax * 2.3841858e-07f * 1.0000002f;
           tau = 1e-9 * (double)smax;
+          tauf = 1.0000001e-9f * smax;
           int32_t hs = a.use_hint ? a.hint[q] : -1;
           if (hs < 0 && a.tcodes)
           {
@@ -951,65 +985,47 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
       }
     }
 
-    // (2) leaves: the cheap bound on each triangle, once enough lanes stand on a leaf (or
-    // nobody can step); a lane whose queue could overflow waits for a screening phase
-    const bool canstep = have && !walked && !atleaf;
-    const bool canleaf = have && !walked && atleaf && npend <= PEND3 - L;
-    const bool anystep = __ballot(canstep) != 0ull;
-    const int nleaf = __popcll(__ballot(canleaf));
-    bool didleaf = false;
-    if (nleaf >= LEAFGO3Q || (!anystep && nleaf > 0))
+    // (2) leaves: both cheap bounds on each triangle, once enough lanes stand on a leaf (or
+    // nobody can step)
+    const bool onleaf = have && !walked && atleaf;
+    const int nleaf = __popcll(__ballot(onleaf));
+    const bool anywalk = __ballot(have && !walked && !atleaf) != 0ull;
+    if (onleaf && (nleaf >= LEAFGO3Q || !anywalk))
     {
-      didleaf = true;
-      if (canleaf)
-      {
-        STAT(1, 1);
-        const int64_t s0 = (int64_t)(n - (1u << d)) * L;
+      STAT(1, 1);
+      // (a lane whose queue could overflow screens it first, on its own: rare)
+      while (npend > PEND3 - L)
+        screen_one();
+      const int64_t s0 = (int64_t)(n - (1u << d)) * L;
+      float lbs[L];
+      float ubmin = FLT_MAX;
 #pragma unroll
-        for (int t = 0; t < L; t++)
-        {
-          const int64_t s = s0 + t;
-          if (s < a.nt && a.tid[s] >= 0 && (int32_t)s != hs_used)
-          {
-            const float lb = tri_lb(a.tpre, s, xf, yf, zf, eabs);
-            if (lb <= boundf)
-            {
-              pend_s[npend][tid] = (int32_t)s;
-              pend_lb[npend][tid] = lb;
-              npend++;
-            }
-          }
-        }
-        need_bt = true;
-        atleaf = false;
-      }
-    }
-
-    // (3) screens: the newest queued triangle of every lane that has one, once enough
-    // lanes do (or nothing else could run this trip)
-    const int nscr = __popcll(__ballot(have && npend > 0));
-    if (nscr >= SCREENGO3 || (!anystep && !didleaf && nscr > 0))
-    {
-      if (have && npend > 0)
+      for (int t = 0; t < L; t++)
       {
-        npend--;
-        const int32_t s = pend_s[npend][tid];
-        if (pend_lb[npend][tid] <= boundf) // (the bound may have tightened since)
+        const int64_t s = s0 + t;
+        lbs[t] = FLT_MAX;
+        if (s < a.nt && a.tid[s] >= 0)
         {
-          STAT(3, 1);
-          d3 P0, P1, P2;
-          load_tri(a.tverts, s, P0, P1, P2);
-          const double d2 = tri_d2_screen(x, P0, P1, P2);
-          if (d2 < best)
-            set_best(d2);
-          if (d2 <= bound)
-          {
-            if (cnt < RING3)
-              ring[cnt][tid] = s;
-            cnt++;
-          }
+          float ub;
+          tri_bounds(a.tpre, s, xf, yf, zf, eabs, lbs[t], ub);
+          ubmin = fminf(ubmin, ub);
         }
       }
+      if (ubmin < ubf)
+      {
+        ubf = ubmin;
+        retighten();
+      }
+#pragma unroll
+      for (int t = 0; t < L; t++)
+        if (lbs[t] <= prunef && (int32_t)(s0 + t) != hs_used)
+        {
+          pend_s[npend][tid] = (int32_t)(s0 + t);
+          pend_lb[npend][tid] = lbs[t];
+          npend++;
+        }
+      need_bt = true;
+      atleaf = false;
     }
   }
 #ifdef ICPX_STATS

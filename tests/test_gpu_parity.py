@@ -277,16 +277,20 @@ def test_midsize_against_grid_oracle(icpx, synth, oracle):
     src = synth.apply(T, pts.astype(np.float64) + noise)
     mesh = oracle.Mesh(xyz, tri)
     ref = mesh.correspond(src, step=1, max_dist=10.0, grid=True)
-    for width, exhaustive, leaf in ((8, False, 2), (64, False, 2), (0, False, 2), (4, False, 2),
-                                    (16, False, 2), (8, True, 2), (1, False, 1), (1, False, 2),
-                                    (1, False, 4)):
+    for width, exhaustive, leaf, pooled in (
+            (8, False, 2, 1), (64, False, 2, 1), (0, False, 2, 1), (4, False, 2, 1), (16, False, 2, 1),
+            (8, True, 2, 1), (1, False, 1, 1), (1, False, 2, 1), (1, False, 4, 1), (1, False, 4, 0),
+            (1, False, 1, 2), (1, False, 2, 2), (1, False, 4, 2)):
         ctx = icpx.Context(0)
         ctx.set_group_width(width)
         ctx.set_exhaustive(exhaustive)
         ctx.set_leaf_size(leaf)
+        ctx.set_persistent(pooled)  # 0 static lanes, 1 pooled, 2 pooled with queued screens
         ctx.set_target(xyz, tri)
         ctx.set_source(src)
-        check_rows(ctx.correspond(np.eye(4), max_dist=10.0), ref)
+        check_rows(ctx.correspond(np.eye(4), max_dist=10.0), ref)          # cold
+        check_rows(ctx.correspond(synth.rigid(rz=0.3), max_dist=10.0),     # hinted, moved
+                   mesh.correspond(src, T=synth.rigid(rz=0.3), step=1, max_dist=10.0, grid=True))
         ctx.close()
 
 
