@@ -70,6 +70,10 @@ def main():
     ap.add_argument("--width", type=int, default=0, help="lanes per query (0 = library default)")
     ap.add_argument("--leaf", type=int, default=0, help="triangles per leaf (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl",
+                    help="process-group backend (gloo + --one-device rehearses N ranks on one GPU)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="development: leave out the HIP events around the search kernels")
     args = ap.parse_args()
@@ -87,11 +91,16 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.one_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     c = make_workload(args.workload, rank, synth)
     nq, nt, nv = len(c["source_xyz"]), len(c["target_tri"]), len(c["target_xyz"])
@@ -121,6 +130,7 @@ def main():
         return T, it, md
 
     def fence():
+        sh.ctx.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -139,7 +149,8 @@ def main():
         raise SystemExit("registration stopped after %d of %d iterations" % (n_iter, args.steps))
     n_acc = sh.ctx.accumulate(metric, T, 1, c["max_dist"])[0]  # outside the timed region
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

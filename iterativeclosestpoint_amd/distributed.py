@@ -21,6 +21,24 @@ def shard_bounds(n_kept, rank, world):
     return n_kept * rank // world, n_kept * (rank + 1) // world
 
 
+def all_reduce_device(t, group=None):
+    """Sum-all-reduce of a small device tensor, ordered on the current stream.  With RCCL
+    (backend "nccl") the collective is a kernel on the device.  Any other backend gets the
+    tensor through a host copy made here: gloo's own handling of device tensors (side
+    streams plus a host wait) stalls when two ranks share one GPU on this ROCm build, with
+    or without this library's kernels in flight (tools/gloo_probe.py shows it with plain
+    torch ops), so it is never handed one."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return
+    host = t.to("cpu")  # stream-ordered copy; returns when the data is on the host
+    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+    t.copy_(host)
+
+
 def make_allreduce(group=None, device_tensor=None):
     """Returns allreduce(sums) for the default/current torch.distributed group, or None when
     the job has a single rank.  With `device_tensor` (a CUDA float64 tensor the sums were
@@ -35,7 +53,7 @@ def make_allreduce(group=None, device_tensor=None):
 
     if device_tensor is not None:
         def reduce_dev(_sums):
-            dist.all_reduce(device_tensor, op=dist.ReduceOp.SUM, group=group)
+            all_reduce_device(device_tensor, group)
             return device_tensor.cpu().numpy()
         return reduce_dev
 
@@ -56,10 +74,16 @@ class ShardedICP:
         self.ctx = icpx.Context(device)
         self.ctx.set_shard(rank, world)
         self.sums_dev = None
+        self.stream = None
         if use_device_allreduce:
+            # The library and the collective share a stream of their own rather than the
+            # default (null) stream and its implicit synchronisation with other streams.
             torch.cuda.set_device(device)
-            self.sums_dev = torch.zeros(icpx.NSUMS, dtype=torch.float64, device="cuda:%d" % device)
-            self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            self.stream = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(self.stream):
+                self.sums_dev = torch.zeros(icpx.NSUMS, dtype=torch.float64,
+                                            device="cuda:%d" % device)
+            self.ctx.set_stream(self.stream.cuda_stream)
 
     def set_target(self, xyz, tri, cell_normals=None):
         self.ctx.set_target(xyz, tri, cell_normals)
@@ -70,9 +94,12 @@ class ShardedICP:
     def iterate(self, metric, T, step, max_dist, min_dot=0.0):
         """One search + partial sums + all-reduce; returns the global sums (numpy)."""
         if self.sums_dev is not None:
+            import torch
+
             self.ctx.accumulate(metric, T, step, max_dist, min_dot,
                                 device_ptr=self.sums_dev.data_ptr())
-            return make_allreduce(self.group, self.sums_dev)(None)
+            with torch.cuda.stream(self.stream):
+                return make_allreduce(self.group, self.sums_dev)(None)
         sums = self.ctx.accumulate(metric, T, step, max_dist, min_dot)
         ar = make_allreduce(self.group)
         return sums if ar is None else ar(sums)
@@ -84,6 +111,7 @@ class ShardedICP:
         Returns (T 4x4, iterations, mean_distance, status), the same on every rank.
         force_collective runs the all-reduce even in a one-rank group (a test of the stream
         ordering between the library's kernels and the collective)."""
+        import torch
         import torch.distributed as dist
 
         assert self.sums_dev is not None, "run_device needs use_device_allreduce=True"
@@ -91,12 +119,13 @@ class ShardedICP:
             (dist.get_world_size(self.group) > 1 or force_collective)
         ptr = self.sums_dev.data_ptr()
         self.ctx.run_begin(params)
-        for _ in range(params.max_iterations):
-            if self.ctx.run_enqueue(ptr):
-                break
-            if multi:
-                dist.all_reduce(self.sums_dev, op=dist.ReduceOp.SUM, group=self.group)
-            self.ctx.run_update(ptr)
+        with torch.cuda.stream(self.stream):
+            for _ in range(params.max_iterations):
+                if self.ctx.run_enqueue(ptr):
+                    break
+                if multi:
+                    all_reduce_device(self.sums_dev, self.group)
+                self.ctx.run_update(ptr)
         return self.ctx.run_end()
 
     def run(self, metric=1, max_iterations=50, max_landmarks=200, max_distance=10.0,
