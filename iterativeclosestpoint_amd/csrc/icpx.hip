@@ -127,7 +127,8 @@ struct icpx_ctx
   Heap heaps[5];  // group kernel's heap-ordered trees
   Bin bins[3];    // lane-per-query kernel's binary trees (1, 2, 4 triangles per leaf)
   int leaf_size = 4;
-  int persistent = 1;
+  int persistent = 4; // 0 static lanes, 1 pooled, 2 pooled + queued screens, 3 one walk per wavefront, 4 by regime
+  int wave_blocks = 16; // blocks per CU of the one-walk-per-wavefront kernel
   int num_cus = 256;
   // hinted shortcut: per-leaf neighbour lists for one radius, and the residual statistics
   // of the previous pass that choose the radius
@@ -654,7 +655,7 @@ extern "C" int icpx_set_persistent(icpx_ctx* c, int enable)
 
   if (!c)
     return fail(ICPX_E_INVALID, "null context");
-  c->persistent = enable < 0 ? 0 : enable > 2 ? 2 : enable;
+  c->persistent = enable < 0 ? 0 : enable > 4 ? 4 : enable;
   return ICPX_OK;
 }
 
@@ -797,7 +798,7 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   if (!rc)
     rc = dev_alloc(&c->d_tid, nt);
   if (!rc)
-    rc = dev_alloc(&c->d_tpre, 2 * nt);
+    rc = dev_alloc(&c->d_tpre, 2 * (nt + TPRE_PAD));
   auto drop_sort = [&]() {
     dev_free(&k0);
     dev_free(&k1);
@@ -815,7 +816,8 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   k_gather_tris<<<nblk(nt, 256), 256, 0, st>>>(
     c->d_xyz, c->d_tri, which ? v1 : v0, nt, c->d_tverts, c->d_tid);
   k_flag_degenerate<<<nblk(nt, 256), 256, 0, st>>>(c->d_tverts, nt, c->d_tid);
-  k_tri_bounds<<<nblk(nt, 256), 256, 0, st>>>(c->d_tverts, nt, c->d_tpre);
+  k_tri_bounds<<<nblk(nt + TPRE_PAD, 256), 256, 0, st>>>(
+    c->d_tverts, c->d_tid, nt, nt + TPRE_PAD, c->d_tpre);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && dev_alloc(&c->d_tcodes, nt) == ICPX_OK)
     e = hipMemcpyAsync(
@@ -1104,9 +1106,11 @@ static int ensure_bin(icpx_ctx* c, int L)
 
 template <int L>
 static void launch_search3(
-  const Search3Args& a, unsigned grid, unsigned pgrid, bool queued, hipStream_t st)
+  const Search3Args& a, unsigned grid, unsigned pgrid, unsigned wgrid, int mode, hipStream_t st)
 {
-  if (pgrid && queued)
+  if (mode == 3)
+    k_search3w<L><<<wgrid, 64, 0, st>>>(a);
+  else if (pgrid && mode == 2)
     k_search3q<L><<<pgrid, 256, 0, st>>>(a);
   else if (pgrid)
     k_search3p<L><<<pgrid, 256, 0, st>>>(a);
@@ -1313,12 +1317,22 @@ static int run_search3(icpx_ctx* c)
     if (pgrid > grid)
       pgrid = grid;
   }
+  // one walk per wavefront: single-wavefront blocks, a resident set of them
+  unsigned wgrid = nblk(c->nq, 64);
+  if (wgrid > (unsigned)c->num_cus * (unsigned)c->wave_blocks)
+    wgrid = (unsigned)c->num_cus * (unsigned)c->wave_blocks;
+  // by regime: a whole pass over a cloud about as dense as the mesh goes one walk per
+  // wavefront (neighbouring queries share their walk); what the shortcut left over, or a
+  // sparse cloud, is scattered and goes one pooled lane per query
+  int mode = c->persistent;
+  if (mode == 4)
+    mode = (!use_local && c->nq * 4 >= c->nt) ? 3 : 1;
   if (L == 1)
-    launch_search3<1>(a, grid, pgrid, c->persistent == 2, st);
+    launch_search3<1>(a, grid, pgrid, wgrid, mode, st);
   else if (L == 2)
-    launch_search3<2>(a, grid, pgrid, c->persistent == 2, st);
+    launch_search3<2>(a, grid, pgrid, wgrid, mode, st);
   else
-    launch_search3<4>(a, grid, pgrid, c->persistent == 2, st);
+    launch_search3<4>(a, grid, pgrid, wgrid, mode, st);
   LAUNCHCHK();
   c->hint_valid = true;
   return ICPX_OK;

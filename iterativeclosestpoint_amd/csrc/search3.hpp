@@ -48,6 +48,7 @@ inline BinTree make_bin_tree(int64_t nt, int L)
   return t;
 }
 
+constexpr int TPRE_PAD = 4; // bounds records past the last triangle (a leaf is read whole)
 constexpr int NODE_FLOATS = 16; // lo0.xyz hi0.xyz lo1.xyz hi1.xyz + 4 pad
 
 // Bottom node level: boxes of the two leaves under node n in [2^(d-1), 2^d).
@@ -107,14 +108,24 @@ __global__ void k_bin_level(int k, float* __restrict__ nodes)
 // Per triangle (Morton position), eight floats: unit normal and the allowance for the
 // stored plane's offset, then centroid and the radius of the circle about it that holds
 // the triangle; for a triangle too thin for its normal to be trusted the normal is zero.
+// The allowance is positive for every triangle that can be a closest cell; records of
+// degenerate triangles and the TPRE_PAD records past the end carry -1 there.
 // From these a query gets a lower bound of its distance to the triangle that, unlike a
 // box's, does not loosen when the triangle is slanted:
 // (distance to the plane)^2 + (in-plane distance to the circle)^2.
-__global__ void k_tri_bounds(const float* __restrict__ tverts, int64_t nt, float4* __restrict__ pre)
+__global__ void k_tri_bounds(const float* __restrict__ tverts, const int32_t* __restrict__ tid,
+  int64_t nt, int64_t npad, float4* __restrict__ pre)
 {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nt)
+  if (s >= npad)
     return;
+  if (s >= nt || tid[s] < 0)
+  {
+    // not a candidate (padding, or a degenerate triangle): a negative allowance says so
+    pre[2 * s] = make_float4(0.f, 0.f, 0.f, -1.f);
+    pre[2 * s + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   d3 P0, P1, P2;
   load_tri(tverts, s, P0, P1, P2);
   const d3 c = mk((P0.x + P1.x + P2.x) / 3.0, (P0.y + P1.y + P2.y) / 3.0,
@@ -725,24 +736,34 @@ constexpr int PEND3 = 8;
 #define LEAFGO3Q 16
 #endif
 
-// lower and upper fp32 bounds of the squared distance from the query to triangle s
-__device__ __forceinline__ void tri_bounds(const float4* __restrict__ pre, int64_t s, float xf,
-  float yf, float zf, float eabs, float& lb, float& ub)
+// lower and upper fp32 bounds of the squared distance from the query to a triangle, from
+// its record {unit normal, plane allowance} {centroid, radius}
+// (RAW: the hardware's square root, within one unit in the last place, which the factors
+// cover as well)
+template <bool RAW = false>
+__device__ __forceinline__ void tri_bounds_rec(float nx, float ny, float nz, float allow, float cx,
+  float cy, float cz, float R, float xf, float yf, float zf, float eabs, float& lb, float& ub)
 {
-  const float4 a = pre[2 * s], b = pre[2 * s + 1];
-  const float vx = xf - b.x, vy = yf - b.y, vz = zf - b.z;
+  const float vx = xf - cx, vy = yf - cy, vz = zf - cz;
   const float q2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
-  const float vlen = __builtin_sqrtf(q2);
-  const float m = 4.f * eabs + a.w + 6.0e-7f * vlen;
-  const float pd = fabsf(__builtin_fmaf(a.z, vz, __builtin_fmaf(a.y, vy, a.x * vx)));
+  const float vlen = RAW ? __builtin_amdgcn_sqrtf(q2) : __builtin_sqrtf(q2);
+  const float m = 4.f * eabs + allow + 6.0e-7f * vlen;
+  const float pd = fabsf(__builtin_fmaf(nz, vz, __builtin_fmaf(ny, vy, nx * vx)));
   const float pd_lo = fmaxf(pd - m, 0.f), pd_hi = pd + m;
   const float vlo = fmaxf(vlen * 0.9999995f - 2.f * eabs, 0.f);
   const float in2 = fmaxf(__builtin_fmaf(vlo, vlo, -(pd_hi * pd_hi)), 0.f);
-  const float ld = fmaxf(__builtin_sqrtf(in2) * 0.9999995f - b.w - 3.f * eabs, 0.f);
+  const float ld =
+    fmaxf((RAW ? __builtin_amdgcn_sqrtf(in2) : __builtin_sqrtf(in2)) * 0.9999995f - R - 3.f * eabs, 0.f);
   lb = __builtin_fmaf(ld, ld, pd_lo * pd_lo) * 0.999999f;
   // the stored centroid is within a rounding of a point of the triangle
   const float vhi = vlen * 1.000001f + 2.f * eabs;
   ub = vhi * vhi * 1.000001f;
+}
+__device__ __forceinline__ void tri_bounds(const float4* __restrict__ pre, int64_t s, float xf,
+  float yf, float zf, float eabs, float& lb, float& ub)
+{
+  const float4 a = pre[2 * s], b = pre[2 * s + 1];
+  tri_bounds_rec(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, xf, yf, zf, eabs, lb, ub);
 }
 
 template <int L>
@@ -1026,6 +1047,384 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
         }
       need_bt = true;
       atleaf = false;
+    }
+  }
+#ifdef ICPX_STATS
+  atomicAdd(&g_stats[0], st_0);
+  atomicAdd(&g_stats[1], st_1);
+  atomicAdd(&g_stats[2], st_2);
+  atomicAdd(&g_stats[3], st_3);
+  atomicAdd(&g_stats[4], st_4);
+  atomicAdd(&g_stats[5], st_5);
+#endif
+}
+
+// The search with one walk per wavefront.  Queries are in Morton order, so the 64 of a
+// wavefront lie within a few triangle widths of each other and their walks visit nearly
+// the same boxes; here the wavefront walks the tree ONCE for all of them.  The node, the
+// stack and the order of descent are the same for every lane (node records and triangle
+// records are read at wavefront-uniform addresses, on the scalar path: one request, not 64
+// scattered ones), while every lane keeps its own query, minimum, bounds and contenders.
+// A box is entered when any lane's bound reaches it.  Two levels are taken per step: the
+// records of both children of a node share a 128-byte line and hold the four
+// grandchildren's boxes, which halves the chain of dependent reads.  Order of descent
+// follows the first interested lane.  At a leaf every lane takes the cheap lower and upper
+// bounds of each triangle (tri_bounds_rec), tightens its bound with the upper one and queues
+// the triangle (per lane, in LDS) if the lower one is within it.  Queued triangles are
+// screened in fp64 when some lane's queue is full and when the walk is over, every lane
+// its own triangle: by then most have dropped out against the tighter bound, and the
+// screen runs with most lanes busy.  Wavefronts draw blocks of 64 queries from
+// counters[2].  Results per query are those of k_search3p: bounds only ever remove
+// triangles that cannot be contenders, and a triangle is a contender by the same per-lane
+// test whatever the order of the walk.
+typedef float vec4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const vec4f cfloat4;
+#ifndef SEEDW
+#define SEEDW 8
+#endif
+constexpr int PENDW = 16; // queue slots per lane (a power of two)
+
+__device__ __forceinline__ uint32_t uni32(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+template <int L>
+__global__ __launch_bounds__(64) void k_search3w(Search3Args a)
+{
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
+  __shared__ int32_t ring[RING3][64];
+  __shared__ int32_t pend_s[PENDW][64];
+  __shared__ uint16_t pend_lb[PENDW][64]; // the lower bound's upper half (rounded towards zero)
+  __shared__ uint32_t stk[96];
+  const int lane = threadIdx.x;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int d = a.tree.depth;
+  const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
+  if ((int64_t)blockIdx.x * 64 >= total)
+    return; // a short list is served by the first blocks; the rest must not queue at the pool
+  // (read-only for the whole launch and addressed uniformly: eligible for the scalar path)
+  cfloat4* nodes4 = (cfloat4*)(uintptr_t)a.nodes;
+  cfloat4* tpre4 = (cfloat4*)(uintptr_t)a.tpre;
+#ifdef ICPX_STATS
+  unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0;
+#endif
+
+  while (true)
+  {
+    uint32_t base = 0;
+    if (lane == 0)
+      base = atomicAdd(&a.counters[2], 64u);
+    base = uni32(base);
+    if ((int64_t)base >= total)
+      break;
+    const int64_t idx = (int64_t)base + lane;
+    const bool active = idx < total;
+    const int64_t q = active ? (a.qlist ? (int64_t)a.qlist[idx] : idx) : 0;
+
+    d3 x = mk(0.0, 0.0, 0.0);
+    float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f, tauf = 0.f;
+    double tau = 0.0, best = DBL_MAX, bound = DBL_MAX;
+    // boundf: from fp64 screens; ubf: smallest cheap upper bound; prunef: what triangles are
+    // tested against (the smaller of the two, the second widened by the tie tolerance);
+    // bboxf: the same for raw box distances (an idle lane's is below every distance)
+    // ubq: squared centroid distance behind ubf; rpf: square root of prunef, rounded up
+    float boundf = FLT_MAX, ubf = FLT_MAX, prunef = FLT_MAX, bboxf = active ? INFINITY : -1.f;
+    float ubq = FLT_MAX, rpf = 1.9e19f;
+    int cnt = 0, npend = 0, phead = 0; // queue: npend entries from slot phead on, oldest first
+    int32_t hs_used = -1;
+
+    auto retighten = [&]() {
+      // (the hardware's square root is within one unit in the last place: the factors
+      // cover it)
+      const float r = __builtin_amdgcn_sqrtf(ubf) * 1.000001f + tauf;
+      prunef = fminf(boundf, r * r * 1.000001f);
+      rpf = __builtin_amdgcn_sqrtf(prunef) * 1.000001f;
+      const float rb_ = rpf + 1.7320509f * eabs; // as box_bound, from the root already at hand
+      bboxf = rb_ * rb_ * 1.000002f;
+    };
+    auto set_best = [&](double nb) {
+      const double r = sqrt(nb) + tau;
+      const double nbound = r * r;
+      if (nbound < best)
+        cnt = 0; // every older contender was above the old minimum
+      best = nb;
+      bound = nbound;
+      boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
+      retighten();
+    };
+    auto screen_one = [&]() { // the oldest queued triangle (nearest leaves come first), if
+                              // it is still in the race
+      const int slot = phead & (PENDW - 1);
+      phead++;
+      npend--;
+      const int32_t s = pend_s[slot][lane];
+      if (__uint_as_float((uint32_t)pend_lb[slot][lane] << 16) <= prunef)
+      {
+        STAT(3, 1);
+        d3 P0, P1, P2;
+        load_tri(a.tverts, s, P0, P1, P2);
+        const double d2 = tri_d2_screen(x, P0, P1, P2);
+        if (d2 < best)
+          set_best(d2);
+        if (d2 <= bound)
+        {
+          if (cnt < RING3)
+            ring[cnt][lane] = s;
+          cnt++;
+        }
+      }
+    };
+
+    if (active)
+    {
+      x = xform(T, a.qpos + 3 * q);
+      xf = (float)x.x;
+      yf = (float)x.y;
+      zf = (float)x.z;
+      const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
+      eabs = smax * 2.3841858e-07f * 1.0000002f;
+      tau = 1e-9 * (double)smax;
+      tauf = 1.0000001e-9f * smax;
+      int32_t hs = a.use_hint ? a.hint[q] : -1;
+      if (hs < 0 && a.tcodes)
+      {
+        // cold start: of the few triangles around the query's place on the Morton curve,
+        // the one with the nearest centroid gives the first bound
+        const uint64_t code = morton63(xf, yf, zf, a.box.lo, a.box.inv);
+        int64_t lo = 0, hi = a.nt; // first position with tcodes[pos] >= code
+        while (lo < hi)
+        {
+          const int64_t mid = (lo + hi) >> 1;
+          if (a.tcodes[mid] < code)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        float qbest = INFINITY;
+#pragma unroll
+        for (int t = -SEEDW / 2; t < SEEDW / 2; t++)
+        {
+          const int64_t sc = min(max(lo + t, (int64_t)0), a.nt - 1);
+          const float4 ra = a.tpre[2 * sc], rb = a.tpre[2 * sc + 1];
+          const float vx = xf - rb.x, vy = yf - rb.y, vz = zf - rb.z;
+          const float q2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
+          if (ra.w >= 0.f && q2 < qbest)
+          {
+            qbest = q2;
+            hs = (int32_t)sc;
+          }
+        }
+      }
+      if (hs >= 0 && a.tid[hs] >= 0)
+      {
+        d3 P0, P1, P2;
+        load_tri(a.tverts, hs, P0, P1, P2);
+        set_best(tri_d2_screen(x, P0, P1, P2));
+        ring[0][lane] = hs;
+        cnt = 1;
+        hs_used = hs;
+      }
+    }
+
+    // sort key of a box for the order of descent: the first interested lane's distance,
+    // the box's number in the two low bits; ~0 for a box nobody wants
+    auto key_of = [&](float lb, unsigned long long m, int rep, uint32_t k) -> uint32_t {
+      const uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lb), rep);
+      return m ? ((bits & ~3u) | k) : 0xffffffffu;
+    };
+
+    int sp = 0;
+    uint32_t n = 1;
+    bool go = true;
+    while (go)
+    {
+      STAT(0, lane == 0 ? 1 : 0);
+      const int lvl = 31 - __clz(n);
+      // the boxes one step down: the two children when they are leaves, else the four
+      // grandchildren (the records of 2n and 2n+1 are one 128-byte line)
+      const bool two = lvl == d - 1;
+      const uint32_t cbase = two ? 2u * n : 4u * n; // heap number of box 0
+      float lb0, lb1, lb2 = 0.f, lb3 = 0.f;
+      unsigned long long m0, m1, m2 = 0ull, m3 = 0ull;
+      if (two)
+      {
+        cfloat4* p = nodes4 + (int64_t)n * 4;
+        const vec4f u = p[0], v = p[1], w = p[2];
+        lb0 = box_d2(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf);
+        lb1 = box_d2(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf);
+        m0 = __ballot(lb0 <= bboxf);
+        m1 = __ballot(lb1 <= bboxf);
+      }
+      else
+      {
+        cfloat4* p = nodes4 + (int64_t)n * 8;
+        const vec4f u = p[0], v = p[1], w = p[2], u2 = p[4], v2 = p[5], w2 = p[6];
+        lb0 = box_d2(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf);
+        lb1 = box_d2(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf);
+        lb2 = box_d2(u2.x, u2.y, u2.z, u2.w, v2.x, v2.y, xf, yf, zf);
+        lb3 = box_d2(v2.z, v2.w, w2.x, w2.y, w2.z, w2.w, xf, yf, zf);
+        m0 = __ballot(lb0 <= bboxf);
+        m1 = __ballot(lb1 <= bboxf);
+        m2 = __ballot(lb2 <= bboxf);
+        m3 = __ballot(lb3 <= bboxf);
+      }
+      const unsigned long long many = m0 | m1 | m2 | m3;
+      uint32_t next = 0;
+      if (many)
+      {
+        const int rep = __ffsll((long long)many) - 1;
+        uint32_t k0 = key_of(lb0, m0, rep, 0u), k1 = key_of(lb1, m1, rep, 1u),
+                 k2 = key_of(lb2, m2, rep, 2u), k3 = key_of(lb3, m3, rep, 3u);
+        uint32_t t_;
+#define CSWAP(A, B)                                                                               \
+  t_ = min(A, B);                                                                                 \
+  B = max(A, B);                                                                                  \
+  A = t_
+        CSWAP(k0, k1);
+        CSWAP(k2, k3);
+        CSWAP(k0, k2);
+        CSWAP(k1, k3);
+        CSWAP(k1, k2);
+#undef CSWAP
+        if (two || lvl + 2 == d)
+        {
+          // leaves, nearest first: cheap bounds of every triangle for the lanes whose bound
+          // reaches the leaf's box
+#pragma nounroll
+          while (k0 != 0xffffffffu)
+          {
+            const uint32_t c = k0 & 3u;
+            k0 = k1;
+            k1 = k2;
+            k2 = k3;
+            k3 = 0xffffffffu;
+            const float lbc = c == 0u ? lb0 : c == 1u ? lb1 : c == 2u ? lb2 : lb3;
+            const bool want = lbc <= bboxf;
+            if (__ballot(want) == 0ull)
+              continue;
+            STAT(1, lane == 0 ? 1 : 0);
+            // room for this leaf in every lane's queue: screen until there is
+            while (__ballot(npend > PENDW - L) != 0ull)
+            {
+              STAT(4, lane == 0 ? 1 : 0);
+              if (npend > 0)
+                screen_one();
+            }
+            const int64_t s0 = (int64_t)(cbase + c - (1u << d)) * L;
+            if (s0 >= a.nt)
+              continue; // a leaf past the last triangle
+#pragma unroll
+            for (int t = 0; t < L; t++)
+            {
+              // (the leaf's records are contiguous, padded past the end, and say themselves
+              // whether the triangle counts)
+              const vec4f ra = tpre4[2 * (s0 + t)], rb = tpre4[2 * (s0 + t) + 1];
+              if (ra.w < 0.f)
+                continue;
+              // first the centroid alone: its distance is an upper bound of the triangle's,
+              // and less the radius a lower one, which for a query many triangle widths
+              // off the surface is nearly as sharp as the plane-and-circle bound
+              const float vx = xf - rb.x, vy = yf - rb.y, vz = zf - rb.z;
+              const float q2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
+              if (active && q2 < ubq)
+              {
+                ubq = q2;
+                const float vhi = __builtin_amdgcn_sqrtf(q2) * 1.000001f + 2.f * eabs;
+                ubf = vhi * vhi * 1.000001f;
+                retighten();
+              }
+              const float reach = rpf + rb.w + 3.f * eabs;
+              const bool near = want && q2 * 0.999998f <= reach * reach * 1.000001f;
+              if (__ballot(near) == 0ull)
+                continue;
+              float lb, ub;
+              tri_bounds_rec<true>(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, xf, yf, zf, eabs,
+                lb, ub);
+              if (near && lb <= prunef && (int32_t)(s0 + t) != hs_used)
+              {
+                const int slot = (phead + npend) & (PENDW - 1);
+                pend_s[slot][lane] = (int32_t)(s0 + t);
+                pend_lb[slot][lane] = (uint16_t)(__float_as_uint(lb) >> 16);
+                npend++;
+              }
+            }
+          }
+        }
+        else
+        {
+          // inner nodes: enter the nearest, owe the others a visit (farthest pushed first)
+          if (lane == 0)
+          {
+            int s_ = sp;
+            if (k3 != 0xffffffffu)
+              stk[s_++] = cbase + (k3 & 3u);
+            if (k2 != 0xffffffffu)
+              stk[s_++] = cbase + (k2 & 3u);
+            if (k1 != 0xffffffffu)
+              stk[s_++] = cbase + (k1 & 3u);
+          }
+          sp += (k3 != 0xffffffffu ? 1 : 0) + (k2 != 0xffffffffu ? 1 : 0) +
+            (k1 != 0xffffffffu ? 1 : 0);
+          next = cbase + (k0 & 3u);
+        }
+      }
+      else
+        STAT(2, lane == 0 ? 1 : 0);
+      if (next)
+        n = next;
+      else if (sp == 0)
+        go = false;
+      else
+      {
+        __builtin_amdgcn_wave_barrier();
+        n = uni32(stk[--sp]);
+      }
+    }
+    // what is still queued, against the bounds as they stand at the end of the walk
+    while (__ballot(npend > 0) != 0ull)
+    {
+      STAT(5, lane == 0 ? 1 : 0);
+      if (npend > 0)
+        screen_one();
+    }
+
+    // settle: a single contender wins outright; 2..RING3 go to the tie list; more overflow
+    const bool tie = active && cnt >= 2 && cnt <= RING3;
+    const bool ovf = active && cnt > RING3;
+    if (active && !tie && !ovf)
+      a.hint[q] = (cnt == 1) ? ring[0][lane] : -1;
+    const unsigned long long mt = __ballot(tie);
+    if (mt)
+    {
+      const int leader = __ffsll((long long)mt) - 1;
+      uint32_t tb = 0;
+      if (lane == leader)
+        tb = atomicAdd(&a.counters[0], (uint32_t)__popcll(mt));
+      tb = __shfl(tb, leader, 64);
+      if (tie)
+      {
+        for (int i = 0; i < RING3; i++)
+          if (i < cnt)
+            a.cand[q * RING3 + i] = ring[i][lane];
+        a.tie_list[tb + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
+      }
+    }
+    const unsigned long long mo = __ballot(ovf);
+    if (mo)
+    {
+      const int leader = __ffsll((long long)mo) - 1;
+      uint32_t ob = 0;
+      if (lane == leader)
+        ob = atomicAdd(&a.counters[1], (uint32_t)__popcll(mo));
+      ob = __shfl(ob, leader, 64);
+      if (ovf)
+      {
+        a.ovf_best[q] = best;
+        a.ovf_list[ob + __popcll(mo & lt)] = (uint32_t)q;
+      }
     }
   }
 #ifdef ICPX_STATS

@@ -280,12 +280,13 @@ def test_midsize_against_grid_oracle(icpx, synth, oracle):
     for width, exhaustive, leaf, pooled in (
             (8, False, 2, 1), (64, False, 2, 1), (0, False, 2, 1), (4, False, 2, 1), (16, False, 2, 1),
             (8, True, 2, 1), (1, False, 1, 1), (1, False, 2, 1), (1, False, 4, 1), (1, False, 4, 0),
-            (1, False, 1, 2), (1, False, 2, 2), (1, False, 4, 2)):
+            (1, False, 1, 2), (1, False, 2, 2), (1, False, 4, 2),
+            (1, False, 1, 3), (1, False, 2, 3), (1, False, 4, 3)):
         ctx = icpx.Context(0)
         ctx.set_group_width(width)
         ctx.set_exhaustive(exhaustive)
         ctx.set_leaf_size(leaf)
-        ctx.set_persistent(pooled)  # 0 static lanes, 1 pooled, 2 pooled with queued screens
+        ctx.set_persistent(pooled)  # 0 static lanes, 1 pooled, 2 pooled + queued screens, 3 one walk per wavefront
         ctx.set_target(xyz, tri)
         ctx.set_source(src)
         check_rows(ctx.correspond(np.eye(4), max_dist=10.0), ref)          # cold

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--leaf", type=int, default=0)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--refill", type=int, default=0)
+    ap.add_argument("--local", type=int, default=1)
+    ap.add_argument("--persistent", type=int, default=-1)
     a = ap.parse_args()
     c = {"c3": synth.config_c3, "c4": synth.config_c4}[a.workload]()
     metric = c["metric"]
@@ -27,6 +29,9 @@ def main():
         ctx.set_leaf_size(a.leaf)
     if a.refill:
         ctx.set_refill(a.refill)
+    if a.persistent >= 0:
+        ctx.set_persistent(a.persistent)
+    ctx.set_local(a.local)
     ctx.set_target(c["target_xyz"], c["target_tri"])
     ctx.set_source(c["source_xyz"], c["source_normals"])
     for rep in range(2):

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--local", type=int, default=1)
     ap.add_argument("--exhaustive", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--refill", type=int, default=0)
     a = ap.parse_args()
     c = {"c3": synth.config_c3, "c4": synth.config_c4}[a.workload]()
     metric = c["metric"]
@@ -41,6 +42,8 @@ def main():
         ctx.set_leaf_size(a.leaf)
         ctx.set_persistent(a.persistent)
         ctx.set_local(a.local)
+        if a.refill:
+            ctx.set_refill(a.refill)
         ctx.set_target(c["target_xyz"], c["target_tri"])
         ctx.set_source(c["source_xyz"], c["source_normals"])
         ctx.accumulate(metric, np.eye(4), 1, c["max_dist"])  # builds tree, sorts queries
