@@ -128,7 +128,7 @@ struct icpx_ctx
   Bin bins[3];    // lane-per-query kernel's binary trees (1, 2, 4 triangles per leaf)
   int leaf_size = 4;
   int persistent = 4; // 0 static lanes, 1 pooled, 2 pooled + queued screens, 3 one walk per wavefront, 4 by regime
-  int wave_blocks = 16; // blocks per CU of the one-walk-per-wavefront kernel
+  int wave_blocks = 19; // blocks per CU of the one-walk-per-wavefront kernel
   int num_cus = 256;
   // hinted shortcut: per-leaf neighbour lists for one radius, and the residual statistics
   // of the previous pass that choose the radius
@@ -149,6 +149,11 @@ struct icpx_ctx
   double last_mean = 0.0;
   int local_holdoff = 0; // passes to go without the shortcut (it served too few queries)
   int bad_streak = 0;    // consecutive passes it served too few queries while the residual was large
+  int holdoff_len = 8;   // length of the next suspension: doubles each time one is called for
+  bool probation = false; // back from a suspension: one more bad pass suspends it again
+  bool last_local = false;   // the pass enqueued last tried the shortcut
+  bool stat_local = false;   // ... and so did the pass whose figures are pending in h_stat
+  bool pass_local[4] = { false, false, false, false }; // ... and the run's passes, by record slot
   // device-resident loop
   RunState* d_state = nullptr;
   RunRecord* h_rec = nullptr; // pinned ring of the last four iterations' records
@@ -637,6 +642,8 @@ extern "C" int icpx_set_local(icpx_ctx* c, int enable)
   c->use_local = enable ? 1 : 0;
   c->local_holdoff = 0; // (and the policy starts afresh)
   c->bad_streak = 0;
+  c->holdoff_len = 8;
+  c->probation = false;
   return ICPX_OK;
 }
 
@@ -676,6 +683,8 @@ extern "C" int icpx_reset_hints(icpx_ctx* c)
   c->stat_pending = false;
   c->local_holdoff = 0;
   c->bad_streak = 0;
+  c->holdoff_len = 8;
+  c->probation = false;
   return ICPX_OK;
 }
 
@@ -1198,13 +1207,18 @@ static int ensure_lists(icpx_ctx* c)
 }
 
 // A finished pass's figures, for the shortcut's policy (see prepare_local).
-static void note_pass(icpx_ctx* c, double n, double mean, double fallback)
+static void note_pass(icpx_ctx* c, double n, double mean, double fallback, bool was_local)
 {
+  if (!was_local)
+    return; // a pass without the shortcut says nothing about it
   const bool bad = n > 0.0 && fallback > 0.5 * (double)c->nq && 3.0 * mean > (double)c->nbr_eps;
   c->bad_streak = bad ? c->bad_streak + 1 : 0;
-  if (c->bad_streak >= 2 && c->local_holdoff == 0)
+  if (!bad && c->local_holdoff == 0)
+    c->probation = false;
+  if (c->bad_streak >= (c->probation ? 1 : 2) && c->local_holdoff == 0)
   {
-    c->local_holdoff = 8;
+    c->local_holdoff = c->holdoff_len;
+    c->holdoff_len = c->holdoff_len < 64 ? 2 * c->holdoff_len : 64;
     c->bad_streak = 0;
   }
 }
@@ -1225,10 +1239,11 @@ static int prepare_local(icpx_ctx* c, bool* use)
   {
     c->stat_pending = false;
     note_pass(c, c->h_stat[0], c->h_stat[0] > 0.0 ? c->h_stat[1] / c->h_stat[0] : 0.0,
-      c->h_stat[2]);
+      c->h_stat[2], c->stat_local);
   }
   if (c->local_holdoff > 0)
   {
+    c->probation = true;
     c->local_holdoff--;
     return ICPX_OK;
   }
@@ -1285,6 +1300,7 @@ static int run_search3(icpx_ctx* c)
   rc = prepare_local(c, &use_local);
   if (rc)
     return rc;
+  c->last_local = use_local;
   ScopedTimer tm(c, 0);
   if (!c->counters_clean)
     HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), st));
@@ -1519,6 +1535,7 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
   {
     HIPCHK(hipEventRecord(c->ev_stat, st));
     c->stat_pending = true;
+    c->stat_local = c->last_local;
   }
   return ICPX_OK;
 }
@@ -1690,6 +1707,8 @@ extern "C" int icpx_run_begin(icpx_ctx* c, const icpx_params* p)
   c->stat_pending = false;
   c->local_holdoff = 0;
   c->bad_streak = 0;
+  c->holdoff_len = 8;
+  c->probation = false;
   double I[16];
   for (int i = 0; i < 16; i++)
     I[i] = (i % 5 == 0) ? 1.0 : 0.0;
@@ -1715,7 +1734,7 @@ static int run_catch_up(icpx_ctx* c)
   const RunRecord& r = c->h_rec[slot];
   if (r.done)
     c->run_done_known = true;
-  note_pass(c, r.n, r.mean, (double)r.fallback);
+  note_pass(c, r.n, r.mean, (double)r.fallback, c->pass_local[slot]);
   return ICPX_OK;
 }
 
@@ -1751,6 +1770,7 @@ extern "C" int icpx_run_update(icpx_ctx* c, const double* sums_device)
     c->d_counters, c->d_rec + slot);
   LAUNCHCHK();
   HIPCHK(hipEventRecord(c->ev_rec[slot], st));
+  c->pass_local[slot] = c->last_local;
   c->run_it++;
   return ICPX_OK;
 }

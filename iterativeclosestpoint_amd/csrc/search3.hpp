@@ -1090,7 +1090,7 @@ __device__ __forceinline__ uint32_t uni32(uint32_t v)
 }
 
 template <int L>
-__global__ __launch_bounds__(64) void k_search3w(Search3Args a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_search3w(Search3Args a)
 {
   Xf T;
   if (!load_xf(a.T, T))
@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(64) void k_search3w(Search3Args a)
   __shared__ int32_t ring[RING3][64];
   __shared__ int32_t pend_s[PENDW][64];
   __shared__ uint16_t pend_lb[PENDW][64]; // the lower bound's upper half (rounded towards zero)
-  __shared__ uint32_t stk[96];
+  __shared__ uint32_t stk[64];
   const int lane = threadIdx.x;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int d = a.tree.depth;
@@ -1316,12 +1316,16 @@ __global__ __launch_bounds__(64) void k_search3w(Search3Args a)
             const int64_t s0 = (int64_t)(cbase + c - (1u << d)) * L;
             if (s0 >= a.nt)
               continue; // a leaf past the last triangle
+            // (the leaf's records are contiguous, padded past the end, and say themselves
+            // whether the triangle counts; all are requested at once)
+            vec4f rec[2 * L];
+#pragma unroll
+            for (int t = 0; t < 2 * L; t++)
+              rec[t] = tpre4[2 * s0 + t];
 #pragma unroll
             for (int t = 0; t < L; t++)
             {
-              // (the leaf's records are contiguous, padded past the end, and say themselves
-              // whether the triangle counts)
-              const vec4f ra = tpre4[2 * (s0 + t)], rb = tpre4[2 * (s0 + t) + 1];
+              const vec4f ra = rec[2 * t], rb = rec[2 * t + 1];
               if (ra.w < 0.f)
                 continue;
               // first the centroid alone: its distance is an upper bound of the triangle's,
