@@ -207,14 +207,21 @@ extern "C"
   /* Hinted shortcut of the lane-per-query path: 1 (default) = once the mean residual is a
    * fraction of the target's edge length, queries close to their previous winner test only
    * the triangles near it (per-triangle neighbour lists, built once per target) instead of
-   * walking the tree; the rest still walk it.  0 = always walk the tree.  Same results. */
+   * walking the tree; the rest still walk it.  A query settled that way with a single
+   * contender also keeps a certificate: a lower bound of how much farther every other
+   * triangle is, less the tie tolerance; while twice its accumulated move stays below that,
+   * later passes keep its winner without searching (a search would return it again).
+   * 2 = the shortcut without certificates.  0 = always walk the tree.  Same results. */
   int icpx_set_local(icpx_ctx* ctx, int enable);
 
-  /* Lane-per-query kernel scheduling: 1 (default) = a resident grid whose lanes draw
-   * queries from a pool as they finish; 0 = one query per lane for the lifetime of a
-   * wavefront; 2 = the pooled kernel with cheap per-triangle lower and upper bounds and
-   * fp64 screens deferred to the end of each walk (ten times fewer screens; faster on
-   * hinted displaced passes, slower on cold ones today).  Same results. */
+  /* Tree kernel of the lane-per-query path.  4 (default) = by regime: a whole pass over a
+   * cloud about as dense as the mesh runs one walk per wavefront (the 64 neighbouring
+   * queries of a wavefront share the walk; node and triangle records are read once per
+   * wavefront), what the shortcut leaves over and sparse clouds run one pooled lane per
+   * query.  3 = always one walk per wavefront; 1 = always pooled lanes (a resident grid
+   * whose lanes draw queries from a pool as they finish); 0 = one query per lane for the
+   * lifetime of a wavefront; 2 = the pooled kernel with cheap per-triangle bounds and fp64
+   * screens deferred to the end of each walk.  Same results. */
   int icpx_set_persistent(icpx_ctx* ctx, int enable);
 
   /* Pooled kernels: how many of a wavefront's 64 lanes must be idle before it takes new
@@ -234,8 +241,11 @@ extern "C"
    * pass (Morton positions of triangles, int32 per query of this shard); 1: Morton
    * position -> cell id (int32 per triangle, -1-id for a degenerate one); 2: {ties,
    * overflows, pool position, shortcut fallbacks} of the last lane-per-query pass (4 x
-   * uint32); 4: {shortcut passes,
-   * tree-only passes, neighbour-list builds, list radius x 1e9, list entries} (5 x int64). */
+   * uint32); 3: screened minima of the queries whose contenders overflowed (double per
+   * query); 4: {shortcut passes, tree-only passes, neighbour-list builds, list radius x
+   * 1e9, list entries} (5 x int64); 5: the shortcut's certificates (float per query of
+   * this shard: how far the query may still move before its winner is looked at again,
+   * 0 = none). */
   int icpx_debug_dump(icpx_ctx* ctx, int what, void* out, int64_t count);
 
   /* Forget the winners of the previous search pass.  A pass normally starts each

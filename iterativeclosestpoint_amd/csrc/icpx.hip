@@ -88,8 +88,21 @@ __global__ void k_set_state(RunState* s, Mat16 T, int reset)
       s->iters = 0;
       s->status = ICPX_RUN_MAX_ITERATIONS;
       s->fallback = 0;
+      s->cert_ok = 0;
     }
   }
+}
+
+// What a pass without the fused sums did to the shortcut's certificates (the fused pass
+// says it in k_reduce_partials).
+__global__ void k_cert_mark(RunState* s, int mode)
+{
+  if (s->done)
+    return;
+  if (mode && threadIdx.x < 12)
+    s->cert_T[threadIdx.x] = s->T[threadIdx.x];
+  if (threadIdx.x == 0)
+    s->cert_ok = mode ? 1 : 0;
 }
 
 __global__ void k_solve(RunState* s, const double* __restrict__ sums, int metric, double ox,
@@ -120,6 +133,7 @@ struct icpx_ctx
   int32_t* d_tid = nullptr;
   uint64_t* d_tcodes = nullptr; // sorted Morton codes of the triangles
   float4* d_tpre = nullptr;     // per-triangle plane bounds
+  float* d_cert = nullptr;      // per query: the shortcut's certificate (see local.hpp)
   float *d_fn = nullptr, *d_en = nullptr, *d_vn = nullptr;
   Box3 box;
   double origin[3] = { 0, 0, 0 };
@@ -149,6 +163,7 @@ struct icpx_ctx
   double last_mean = 0.0;
   int local_holdoff = 0; // passes to go without the shortcut (it served too few queries)
   int bad_streak = 0;    // consecutive passes it served too few queries while the residual was large
+  int use_cert = 1;      // the shortcut keeps certificates (icpx_set_local(2) turns them off)
   int holdoff_len = 8;   // length of the next suspension: doubles each time one is called for
   bool probation = false; // back from a suspension: one more bad pass suspends it again
   bool last_local = false;   // the pass enqueued last tried the shortcut
@@ -377,6 +392,7 @@ static void free_queries(icpx_ctx* c)
   dev_free(&c->d_ovf_list);
   dev_free(&c->d_ovf_best);
   dev_free(&c->d_fallback);
+  dev_free(&c->d_cert);
   c->q_cap = 0;
   c->q3_cap = 0;
   c->prep_step = -1;
@@ -454,6 +470,8 @@ extern "C" int icpx_create(icpx_ctx** out, int device)
     rc = fail(ICPX_E_HIP, "hipEventCreate failed");
   if (!rc)
     rc = dev_alloc(&c->d_state, 1);
+  if (!rc && hipMemset(c->d_state, 0, sizeof(RunState)) != hipSuccess)
+    rc = fail(ICPX_E_HIP, "hipMemset failed");
 
   if (!rc &&
     (hipHostMalloc((void**)&c->h_rec, sizeof(RunRecord) * 4,
@@ -606,6 +624,11 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
     src = c->d_ovf_best;
     bytes = sizeof(double) * (size_t)std::min<int64_t>(count, c->nq);
   }
+  else if (what == 5 && c->d_cert)
+  {
+    src = c->d_cert;
+    bytes = sizeof(float) * (size_t)std::min<int64_t>(count, c->nq);
+  }
   if (!src)
     return fail(ICPX_E_INVALID, "nothing to dump");
   HIPCHK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
@@ -640,6 +663,7 @@ extern "C" int icpx_set_local(icpx_ctx* c, int enable)
   if (!c)
     return fail(ICPX_E_INVALID, "null context");
   c->use_local = enable ? 1 : 0;
+  c->use_cert = enable == 2 ? 0 : 1; // 2: the shortcut without its certificates
   c->local_holdoff = 0; // (and the policy starts afresh)
   c->bad_streak = 0;
   c->holdoff_len = 8;
@@ -1269,6 +1293,7 @@ static int run_search3(icpx_ctx* c)
     ALLOC(c->d_ovf_list, c->nq);
     ALLOC(c->d_ovf_best, c->nq);
     ALLOC(c->d_fallback, c->nq);
+    ALLOC(c->d_cert, c->nq);
     c->q3_cap = c->nq;
   }
   const Bin& b = c->bins[(L == 1) ? 0 : (L == 2) ? 1 : 2];
@@ -1318,6 +1343,9 @@ static int run_search3(icpx_ctx* c)
     la.grid = c->qgrid;
     la.eps = c->nbr_eps;
     la.fallback = c->d_fallback;
+    la.cert = c->use_cert ? c->d_cert : nullptr;
+    la.cert_T = c->d_state->cert_T;
+    la.cert_ok = &c->d_state->cert_ok;
     k_search_local<<<grid, 256, 0, st>>>(la);
     a.qlist = c->d_fallback; // the tree kernel serves what is left,
     a.use_hint = 1;          // starting from the triangles the shortcut reached
@@ -1363,6 +1391,7 @@ static void launch_search2(const Search2Args& a, unsigned grid, hipStream_t st)
 
 static int run_search(icpx_ctx* c)
 {
+  c->last_local = false;
   const int G = pick_width(c);
   if (G == 1)
     return run_search3(c);
@@ -1527,7 +1556,8 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
       k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
   }
   k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, &c->d_state->done,
-    c->d_counters, want_stat ? c->d_stat : nullptr);
+    c->d_counters, want_stat ? c->d_stat : nullptr, c->d_state->T, c->d_state->cert_T,
+    &c->d_state->cert_ok, (c->last_local && c->use_cert) ? 1 : 0);
   LAUNCHCHK();
   if (c->d_counters)
     c->counters_clean = true;
@@ -1611,6 +1641,7 @@ extern "C" int icpx_correspond(icpx_ctx* c, const double T[16], int64_t step, do
     rc = run_search(c);
   if (rc)
     return rc;
+  k_cert_mark<<<1, 64, 0, c->stream>>>(c->d_state, (c->last_local && c->use_cert) ? 1 : 0);
   FinalArgs f;
   fill_final(c, f, max_dist, min_dot, use_sn, use_sn != 0);
   f.o_origin = c->r_origin;

@@ -218,6 +218,11 @@ struct LocalArgs
   QuantGrid grid;
   float eps;            // radius the lists were built for
   uint32_t* fallback;   // queries left to the tree kernel; their count is counters[3]
+  // certificates: per query, how far it may still move before last pass's winner has to be
+  // looked at again (0: no certificate); the transform they refer to; whether they count
+  float* cert;
+  const double* cert_T;
+  const int32_t* cert_ok;
 };
 
 constexpr int LOCAL_STEPS = 16; // moves along the surface before a query is given up
@@ -230,12 +235,45 @@ constexpr int LOCAL_PEND = 6;   // triangles a lane may hold for the screening l
 // ends); a query that arrives within eps/2 of a triangle is settled from that triangle's
 // list alone, the others are handed to the tree kernel with the triangle they reached as
 // their starting bound.  Every query's slot in hint[] is rewritten.
-__global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
+//
+// Certificates.  A query settled here with a single contender w also learns how far every
+// other triangle is at least: the boxes and edge half-spaces that ruled listed triangles
+// out are lower bounds of their distances, screened ones have their distance, and a
+// triangle outside the list is farther than eps less the distance to the list's owner.
+// The smallest of these less the distance to w, less the tie tolerance, is the query's
+// slack: as long as the query has moved by less than half of it since (distances to a
+// triangle change by at most the move), w is still the only contender, and the search
+// would return it again.  Later passes only subtract twice the move from the slack of such
+// a query and leave its hint alone; the search runs again when the slack is used up.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_search_local(LocalArgs la)
 {
   const Search3Args& a = la.s;
-  Xf T;
-  if (!load_xf(a.T, T))
+  // everything that is the same for all lanes is requested at once, ahead of the test of
+  // the stop flag: a pass that lets most queries through on their certificates is only as
+  // long as its chain of dependent reads
+  Xf T, Tc;
+  const int32_t stopv = a.T.stop ? *a.T.stop : 0;
+  int32_t okv = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++)
+    T.m[i] = a.T.T[i];
+  if (la.cert)
+  {
+    okv = *la.cert_ok;
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+      Tc.m[i] = la.cert_T[i];
+  }
+  else
+    Tc = T;
+  if (__builtin_amdgcn_readfirstlane(stopv) != 0)
     return; // the registration this pass belongs to has already stopped
+#pragma unroll
+  for (int i = 0; i < 12; i++)
+  {
+    T.m[i] = uniform_f64(T.m[i]);
+    Tc.m[i] = uniform_f64(Tc.m[i]);
+  }
   __shared__ int32_t ring[RING3][256];
   __shared__ int32_t pendq[LOCAL_PEND][256];
   __shared__ uint32_t wcount[4];
@@ -253,7 +291,9 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
   const float ginv2 = la.grid.inv_step * la.grid.inv_step * 1.00001f;
   int cnt = 0;
   int32_t hs = -1;
-  bool local = false;
+  bool local = false, certified = false;
+  float sec2 = 0.f; // lower bound of the squared distance of every triangle but the best
+  const bool cert_on = la.cert && a.use_hint && __builtin_amdgcn_readfirstlane(okv) != 0;
 
   auto set_best = [&](double nb) {
     const double r = sqrt(nb) + tau;
@@ -269,6 +309,7 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
   uint32_t e = 0, eend = 0;
   if (active)
   {
+    const float slack = cert_on ? la.cert[q] : 0.f; // (requested together with the point)
     x = xform(T, a.qpos + 3 * q);
     xf = (float)x.x;
     yf = (float)x.y;
@@ -276,8 +317,28 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
     const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
     eabs = smax * 2.3841858e-07f * 1.0000002f;
     tau = 1e-9 * (double)smax;
-    hs = a.use_hint ? a.hint[q] : -1;
-    if (hs < 0 && a.tcodes)
+    if (cert_on)
+    {
+      if (slack > 0.f)
+      {
+        // the move since the certificate was last brought up to date
+        const d3 xp = xform(Tc, a.qpos + 3 * q);
+        const double mx = x.x - xp.x, my = x.y - xp.y, mz = x.z - xp.z;
+        const float m2 = __double2float_ru(mx * mx + my * my + mz * mz);
+        const float mv = __builtin_amdgcn_sqrtf(m2) * 1.000001f;
+        const float left = slack - 2.000001f * mv - 1e-30f;
+        if (left > 0.f)
+        {
+          certified = true;
+          la.cert[q] = left * 0.9999999f;
+        }
+      }
+    }
+    hs = (a.use_hint && !certified) ? a.hint[q] : -1;
+  }
+  if (active)
+  {
+    if (hs < 0 && a.tcodes && !certified)
     {
       const uint64_t code = morton63(xf, yf, zf, a.box.lo, a.box.inv);
       int64_t lo = 0, hi = a.nt; // first position with tcodes[pos] >= code
@@ -319,6 +380,10 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
           best = DBL_MAX;
           set_best(d2);
           local = true;
+          // a triangle outside this list is farther than eps from this triangle's box,
+          // which the query is within sqrt(d2) of
+          const float out = la.eps - __double2float_ru(sqrt(d2)) * 1.000001f - 4.f * eabs;
+          sec2 = out > 0.f ? out * out * 0.999999f : 0.f;
           break;
         }
       }
@@ -364,7 +429,7 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
   // queries this kernel cannot settle go to the tree kernel, with the triangle they
   // reached as their hint; one atomic per block
   {
-    const bool fb = active && !local;
+    const bool fb = active && !local && !certified;
     const unsigned long long mf = __ballot(fb);
     if (lane == 0)
       wcount[tid >> 6] = (uint32_t)__popcll(mf);
@@ -391,11 +456,14 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
   // survive are held back and screened after the scan, so that the fp64 screen runs once
   // or twice per wavefront instead of once per "some lane's box passed".
   const float alw = 6.f * eabs;
+  const float step2lo = la.grid.step * la.grid.step * 0.99999f; // grid steps^2 -> length^2, rounded down
   int npend = 0;
   auto screen = [&](int32_t s) {
     d3 P0, P1, P2;
     load_tri(a.tverts, s, P0, P1, P2);
     const double d2 = tri_d2_screen(x, P0, P1, P2);
+    // whichever of this triangle and the best so far loses is one of "the others"
+    sec2 = fminf(sec2, __double2float_rd(fmax(d2, best)) * 0.999999f);
     if (d2 < best)
       set_best(d2);
     if (d2 <= bound)
@@ -422,11 +490,22 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
     for (int k = 0; k < 8; k++)
     {
       const int32_t s = m[k];
-      if (s < 0 || s == hs || qbox_g2(wq[k], gx, gy, gz) > boundg)
+      if (s < 0 || s == hs)
         continue;
+      const float g2 = qbox_g2(wq[k], gx, gy, gz);
+      if (g2 > boundg)
+      {
+        sec2 = fminf(sec2, g2 * step2lo); // ruled out by its box: at least that far
+        continue;
+      }
       const float ex = edge_excess(la.edges, s, xf, yf, zf, alw);
-      if ((ex > 0.f && ex * ex * 0.999999f > boundf) || a.tid[s] < 0)
-        continue; // outside an edge by more than the bound / degenerate
+      if (a.tid[s] < 0)
+        continue; // degenerate: never a closest cell
+      if (ex > 0.f && ex * ex * 0.999999f > boundf)
+      {
+        sec2 = fminf(sec2, ex * ex * 0.999999f); // outside an edge by more than the bound
+        continue;
+      }
       if (npend < LOCAL_PEND)
         pendq[npend++][tid] = s;
       else
@@ -435,6 +514,30 @@ __global__ __launch_bounds__(256) void k_search_local(LocalArgs la)
   }
   for (int i = 0; i < npend; i++)
     screen(pendq[i][tid]);
+
+  // the certificate of a query settled with a single contender; none for any other query
+  // that was looked at
+  if (la.cert && active && !certified)
+  {
+    float slack = 0.f;
+    if (local && cnt == 1)
+      slack = __builtin_amdgcn_sqrtf(sec2) * 0.999999f - __double2float_ru(sqrt(best)) * 1.000001f -
+        2.1f * (float)tau - eabs;
+    la.cert[q] = fmaxf(slack, 0.f);
+  }
+
+#ifdef ICPX_STATS
+  {
+    // development build only: queries let through on their certificate / given a new one
+    const unsigned long long mc = __ballot(certified);
+    const unsigned long long mn = __ballot(la.cert && active && !certified && la.cert[q] > 0.f);
+    if (lane == 0)
+    {
+      atomicAdd(&g_stats[6], (unsigned long long)__popcll(mc));
+      atomicAdd(&g_stats[7], (unsigned long long)__popcll(mn));
+    }
+  }
+#endif
 
   // settle (as the tree kernel does)
   const bool tie = local && cnt >= 2 && cnt <= RING3;

@@ -487,13 +487,24 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))
 // Block partials -> the ICPX_NSUMS totals.  One 64-lane block per sum: lane l adds
 // partials l, l+64, ... in that order, then a fixed xor-shuffle tree; the shape
 // depends only on the number of blocks, so results repeat run to run.
+// cert_mode says what the pass did to the shortcut's certificates: 1 brought them up to
+// date for the transform T (recorded in cert_T), 0 left them behind (cert_ok is cleared).
 __global__ __launch_bounds__(64) void k_reduce_partials(
   const double* __restrict__ partials, int nblocks, double* __restrict__ sums,
-  const int32_t* __restrict__ stop, uint32_t* __restrict__ counters, double* __restrict__ stat)
+  const int32_t* __restrict__ stop, uint32_t* __restrict__ counters, double* __restrict__ stat,
+  const double* __restrict__ T, double* __restrict__ cert_T, int32_t* __restrict__ cert_ok,
+  int cert_mode)
 {
   if (stop && *stop)
     return; // the pass did not run
   const int i = blockIdx.x, l = threadIdx.x;
+  if (cert_ok && i == 1)
+  {
+    if (cert_mode && l < 12)
+      cert_T[l] = T[l];
+    if (l == 0)
+      *cert_ok = cert_mode ? 1 : 0;
+  }
   if (counters && i == 0 && l < 4)
   {
     // the search kernels' four pass counters move up for whoever wants to look at them,

@@ -17,6 +17,11 @@ struct RunState
   int32_t status;  // ICPX_RUN_*
   int32_t done;    // 1: converged / too few rows; later passes return at once
   uint32_t fallback; // queries the shortcut left to the tree walk in the last pass
+  // ---- the shortcut's certificates (local.hpp): the transform they were last brought up
+  // to date for (rows 0..2), and whether they are up to date at all
+  double cert_T[12];
+  int32_t cert_ok;
+  int32_t pad_;
 };
 struct RunRecord
 {

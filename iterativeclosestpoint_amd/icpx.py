@@ -163,7 +163,8 @@ class Context:
         _chk(load().icpx_synchronize(self._h))
 
     def set_local(self, enable=True):
-        _chk(load().icpx_set_local(self._h, int(bool(enable))))
+        """True/1: the shortcut with certificates; 2: without certificates; False/0: tree only."""
+        _chk(load().icpx_set_local(self._h, int(enable)))
 
     def debug_stats(self):
         """{shortcut passes, tree-only passes, neighbour-list builds, list radius}."""
@@ -177,6 +178,12 @@ class Context:
         v = np.zeros(4, np.uint32)
         _chk(load().icpx_debug_dump(self._h, 2, _p(v), 4))
         return dict(ties=int(v[0]), overflows=int(v[1]), pool=int(v[2]), fallback=int(v[3]))
+
+    def debug_certificates(self, n):
+        """The shortcut's certificates of the first n queries (in the library's query order)."""
+        v = np.zeros(int(n), np.float32)
+        _chk(load().icpx_debug_dump(self._h, 5, _p(v), int(n)))
+        return v
 
     def set_persistent(self, enable=True):
         _chk(load().icpx_set_persistent(self._h, int(enable)))

@@ -685,6 +685,42 @@ def test_shortcut_on_triangle_soup(icpx, synth, oracle, seed):
     assert ctxs[0].debug_stats()["local_passes"] >= 6
 
 
+def test_certificates_change_nothing(icpx, synth, oracle):
+    """A drifting registration-like sequence of poses, from moves far below the triangle size
+    to moves beyond it: the shortcut with certificates (winners kept without a search while
+    the accumulated move stays inside the certified slack), the shortcut without them and
+    the tree alone return bit-identical rows in every pass, and those are the oracle's."""
+    xyz, tri = synth.bumpy_torus(240, 120)
+    pts, f, fn = synth.sample_surface(xyz, tri, 70_000, seed=21)
+    off = np.stack([synth.gaussian(5, 90 + 2 * k, len(pts)) for k in range(3)], -1)
+    scale = np.where(synth.u01(5, 96, len(pts)) < 0.7, 0.0, 10.0 ** (-7 + 4 * synth.u01(5, 97, len(pts))))
+    src = (pts.astype(np.float64) + off * scale[:, None]).astype(np.float32)
+    mesh = oracle.Mesh(xyz, tri)
+    ctxs = []
+    for local in (1, 2, 0):
+        c_ = icpx.Context(0)
+        c_.set_group_width(1)
+        c_.set_local(local)
+        c_.set_target(xyz, tri)
+        c_.set_source(src)
+        ctxs.append(c_)
+    moves = [0, 0, 1e-8, 3e-8, 1e-7, 1e-7, 1e-6, 1e-8, 1e-5, 1e-8, 1e-4, 1e-8, 1e-8, 2e-3, 1e-8, 1e-8]
+    T = np.eye(4)
+    kept = []
+    for i, m in enumerate(moves):
+        T = synth.rigid(rx=20 * m, rz=-30 * m, t=(m, -0.5 * m, 0.25 * m)) @ T
+        rows = [c_.correspond(T, step=1, max_dist=10.0) for c_ in ctxs]
+        check_rows(rows[0], rows[1])
+        check_rows(rows[0], rows[2])
+        if i in (0, 3, 7, 11, 15):
+            check_rows(rows[0], mesh.correspond(src, T=T, step=1, max_dist=10.0, grid=True))
+        sums = [c_.accumulate(1, T, step=1, max_dist=10.0) for c_ in ctxs]  # and a fused pass
+        assert np.array_equal(sums[0], sums[1]) and np.array_equal(sums[0], sums[2])
+        kept.append(float((ctxs[0].debug_certificates(len(src)) > 0).mean()))
+    assert ctxs[0].debug_stats()["local_passes"] >= 20
+    assert min(kept[2:8]) > 0.9 and kept[-1] > 0.9  # most queries hold a certificate
+
+
 def _sharded_rank(rank, world, port, metric, out):
     """One rank of test_sharded_device_loop_two_ranks (spawned)."""
     import torch.distributed as dist

@@ -66,6 +66,8 @@ def main():
                       "  per wavefront: loop trips %.0f refills %.1f" %
                       (st[0] / nq, st[2] / nq, st[1] / nq, st[3] / nq, st[4] / (nq / 64),
                        st[5] / (nq / 64)))
+                print("   shortcut: let through on certificate %.4f of the queries, newly certified %.4f" %
+                      (st[6] / nq, st[7] / nq))
             return min(ts), float(np.median(ts))
         cold = timed(np.eye(4), True)
         hot0 = timed(np.eye(4), False)
