@@ -257,7 +257,9 @@ extern "C"
   /* Measurement aid (no reference counterpart): record HIP events on the
    * context's stream around every launch of the search kernel and of the
    * finalize/reduction kernel.  icpx_get_timing synchronises and returns the
-   * accumulated kernel milliseconds and launch counts since timing was enabled. */
+   * accumulated kernel milliseconds and launch counts since timing was enabled.
+   * enable = 2 times the search kernels only (every event is a marker in the queue that
+   * costs a few microseconds between launches). */
   int icpx_set_timing(icpx_ctx* ctx, int enable);
   int icpx_get_timing(icpx_ctx* ctx, double* search_ms, int64_t* search_launches,
     double* finalize_ms, int64_t* finalize_launches);

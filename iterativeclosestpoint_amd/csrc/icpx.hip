@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -107,7 +108,7 @@ __global__ void k_cert_mark(RunState* s, int mode)
 
 __global__ void k_solve(RunState* s, const double* __restrict__ sums, int metric, double ox,
   double oy, double oz, int check_mean, double max_mean, const uint32_t* __restrict__ counters,
-  RunRecord* rec)
+  RunRecord* rec, uint32_t seq)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0)
     return;
@@ -117,7 +118,43 @@ __global__ void k_solve(RunState* s, const double* __restrict__ sums, int metric
     s->fallback = counters ? counters[7] : 0u; // snapshot of the pass's fallback count
     solve_step(s, sums, metric, origin, check_mean, max_mean);
   }
-  publish_record(s, rec);
+  publish_record(s, rec, seq);
+}
+
+// The reduction and the solve in one launch, for a loop with nothing between them (one
+// rank): the block that finishes its sum last takes the ICPX_NSUMS totals and advances the
+// registration as k_solve does.  *ticket counts finished blocks and is left at zero.
+__global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ partials,
+  int nblocks, double* sums, uint32_t* __restrict__ counters, RunState* s, int cert_mode,
+  int metric, double ox, double oy, double oz, int check_mean, double max_mean, RunRecord* rec,
+  uint32_t seq, uint32_t* ticket)
+{
+  __shared__ double tot[ICPX_NSUMS];
+  __shared__ uint32_t last;
+  const bool ran = reduce_partials_body(partials, nblocks, sums, &s->done, counters, nullptr, s->T,
+    s->cert_T, &s->cert_ok, cert_mode);
+  if (threadIdx.x == 0)
+  {
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last)
+    return;
+  __threadfence();
+  if (threadIdx.x < ICPX_NSUMS)
+    tot[threadIdx.x] = *reinterpret_cast<volatile double*>(sums + threadIdx.x);
+  __syncthreads();
+  if (threadIdx.x != 0)
+    return;
+  *ticket = 0u;
+  if (ran && !s->done)
+  {
+    const double origin[3] = { ox, oy, oz };
+    s->fallback = counters ? counters[7] : 0u; // snapshot of the pass's fallback count
+    solve_step(s, tot, metric, origin, check_mean, max_mean);
+  }
+  publish_record(s, rec, seq);
 }
 
 struct icpx_ctx
@@ -134,6 +171,7 @@ struct icpx_ctx
   uint64_t* d_tcodes = nullptr; // sorted Morton codes of the triangles
   float4* d_tpre = nullptr;     // per-triangle plane bounds
   float* d_cert = nullptr;      // per query: the shortcut's certificate (see local.hpp)
+  uint32_t* d_ticket = nullptr; // k_reduce_solve's count of finished blocks (zero between launches)
   float *d_fn = nullptr, *d_en = nullptr, *d_vn = nullptr;
   Box3 box;
   double origin[3] = { 0, 0, 0 };
@@ -175,7 +213,8 @@ struct icpx_ctx
   RunRecord* d_rec = nullptr; // the same memory as the device sees it
   double* d_stat = nullptr;   // h_stat as the device sees it
   bool counters_clean = false; // the pass counters are zero (the reduction left them so)
-  hipEvent_t ev_rec[4] = { nullptr, nullptr, nullptr, nullptr };
+  uint32_t rec_seq = 0;                      // serial number of the last solve enqueued
+  uint32_t slot_seq[4] = { 0, 0, 0, 0 };     // ... and of the solve that writes each record slot
   bool run_active = false, run_done_known = false;
   int64_t run_it = 0, run_step = 1;
   icpx_params run_p;
@@ -231,7 +270,7 @@ struct icpx_ctx
   void* allreduce_user = nullptr;
 
   // optional HIP-event timing of the two hot kernels
-  bool timing = false;
+  int timing = 0; // 0 off, 1 both hot kernels, 2 the search kernels only
   struct Pending
   {
     hipEvent_t a, b;
@@ -284,7 +323,7 @@ struct ScopedTimer
     : c(ctx)
     , which(w)
   {
-    if (!c->timing)
+    if (!c->timing || (c->timing == 2 && which != 0))
       return;
     if (c->pending.size() >= 4096)
     {
@@ -298,7 +337,7 @@ struct ScopedTimer
   }
   ~ScopedTimer()
   {
-    if (!c->timing)
+    if (!a && !b)
       return;
     if (b)
       (void)hipEventRecord(b, c->stream);
@@ -472,15 +511,18 @@ extern "C" int icpx_create(icpx_ctx** out, int device)
     rc = dev_alloc(&c->d_state, 1);
   if (!rc && hipMemset(c->d_state, 0, sizeof(RunState)) != hipSuccess)
     rc = fail(ICPX_E_HIP, "hipMemset failed");
+  if (!rc)
+    rc = dev_alloc(&c->d_ticket, 1);
+  if (!rc && hipMemset(c->d_ticket, 0, sizeof(uint32_t)) != hipSuccess)
+    rc = fail(ICPX_E_HIP, "hipMemset failed");
 
   if (!rc &&
     (hipHostMalloc((void**)&c->h_rec, sizeof(RunRecord) * 4,
        hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->d_rec, c->h_rec, 0) != hipSuccess))
     rc = fail(ICPX_E_NOMEM, "hipHostMalloc failed");
-  for (int i = 0; i < 4 && !rc; i++)
-    if (hipEventCreateWithFlags(&c->ev_rec[i], hipEventDisableTiming) != hipSuccess)
-      rc = fail(ICPX_E_HIP, "hipEventCreate failed");
+  if (!rc)
+    std::memset(c->h_rec, 0, sizeof(RunRecord) * 4);
   if (rc)
   {
     icpx_destroy(c);
@@ -511,11 +553,9 @@ extern "C" void icpx_destroy(icpx_ctx* c)
   if (c->ev_stat)
     (void)hipEventDestroy(c->ev_stat);
   dev_free(&c->d_state);
+  dev_free(&c->d_ticket);
   if (c->h_rec)
     (void)hipHostFree(c->h_rec);
-  for (auto e : c->ev_rec)
-    if (e)
-      (void)hipEventDestroy(e);
   resolve_timing(c);
   for (auto e : c->free_events)
     (void)hipEventDestroy(e);
@@ -561,7 +601,7 @@ extern "C" int icpx_set_timing(icpx_ctx* c, int enable)
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
   resolve_timing(c);
-  c->timing = enable != 0;
+  c->timing = enable < 0 ? 0 : enable > 2 ? 2 : enable;
   c->t_ms[0] = c->t_ms[1] = 0.0;
   c->t_n[0] = c->t_n[1] = 0;
   return ICPX_OK;
@@ -1523,7 +1563,7 @@ static int check_call(icpx_ctx* c, const double* T, int metric, int use_sn)
 // the device state.  `stat` asks for the pass's {n, sum |s-t|} to be copied to the host
 // behind an event (for callers that do not run the device-resident loop).
 static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, double min_dot,
-  int use_sn, double* dst, bool stat)
+  int use_sn, double* dst, bool stat, bool fuse_solve = false)
 {
   int rc = prepare_queries(c, step);
   if (rc)
@@ -1555,9 +1595,23 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     else
       k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
   }
-  k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, &c->d_state->done,
-    c->d_counters, want_stat ? c->d_stat : nullptr, c->d_state->T, c->d_state->cert_T,
-    &c->d_state->cert_ok, (c->last_local && c->use_cert) ? 1 : 0);
+  const int cert_mode = (c->last_local && c->use_cert) ? 1 : 0;
+  if (fuse_solve)
+  {
+    // (a run's pass on one rank: the solve rides on the reduction's launch)
+    const icpx_params& p = c->run_p;
+    const int slot = (int)(c->run_it & 3);
+    k_reduce_solve<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, c->d_counters, c->d_state,
+      cert_mode, p.metric, c->origin[0], c->origin[1], c->origin[2], p.check_mean_distance,
+      p.max_mean_distance, c->d_rec + slot, ++c->rec_seq, c->d_ticket);
+    c->slot_seq[slot] = c->rec_seq;
+    c->pass_local[slot] = c->last_local;
+    c->run_it++;
+  }
+  else
+    k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, &c->d_state->done,
+      c->d_counters, want_stat ? c->d_stat : nullptr, c->d_state->T, c->d_state->cert_T,
+      &c->d_state->cert_ok, cert_mode);
   LAUNCHCHK();
   if (c->d_counters)
     c->counters_clean = true;
@@ -1761,7 +1815,23 @@ static int run_catch_up(icpx_ctx* c)
   if (c->run_it < 2)
     return ICPX_OK;
   const int slot = (int)((c->run_it - 2) & 3);
-  HIPCHK(hipEventSynchronize(c->ev_rec[slot]));
+  // wait for that solve's serial number to show up in the pinned record (the GPU writes it
+  // last); while waiting, look now and then whether the stream has drained without it
+  const uint32_t want = c->slot_seq[slot];
+  volatile const uint32_t* seen = &c->h_rec[slot].seq;
+  for (uint64_t spins = 0; *seen != want; spins++)
+  {
+    if ((spins & 0xfffff) == 0xfffff)
+    {
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipSuccess && *seen != want)
+        return fail(ICPX_E_HIP, "iteration record %u never arrived", want);
+      if (e != hipSuccess && e != hipErrorNotReady)
+        return fail(ICPX_E_HIP, "stream failed: %s", hipGetErrorString(e));
+    }
+    __builtin_ia32_pause();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
   const RunRecord& r = c->h_rec[slot];
   if (r.done)
     c->run_done_known = true;
@@ -1769,7 +1839,7 @@ static int run_catch_up(icpx_ctx* c)
   return ICPX_OK;
 }
 
-extern "C" int icpx_run_enqueue(icpx_ctx* c, double* sums_device, int* done_out)
+static int run_enqueue_impl(icpx_ctx* c, double* sums_device, int* done_out, bool fuse_solve)
 {
   if (!c || !c->run_active)
     return fail(ICPX_E_INVALID, "icpx_run_enqueue: no run in progress (call icpx_run_begin)");
@@ -1783,7 +1853,13 @@ extern "C" int icpx_run_enqueue(icpx_ctx* c, double* sums_device, int* done_out)
     return ICPX_OK;
   const icpx_params& p = c->run_p;
   return enqueue_pass(c, p.metric, c->run_step, p.max_distance, p.min_normal_dot,
-    p.metric == ICPX_METRIC_PLANE_TO_PLANE ? 1 : 0, sums_device ? sums_device : c->d_sums, false);
+    p.metric == ICPX_METRIC_PLANE_TO_PLANE ? 1 : 0, sums_device ? sums_device : c->d_sums, false,
+    fuse_solve);
+}
+
+extern "C" int icpx_run_enqueue(icpx_ctx* c, double* sums_device, int* done_out)
+{
+  return run_enqueue_impl(c, sums_device, done_out, false);
 }
 
 extern "C" int icpx_run_update(icpx_ctx* c, const double* sums_device)
@@ -1798,9 +1874,9 @@ extern "C" int icpx_run_update(icpx_ctx* c, const double* sums_device)
   const int slot = (int)(c->run_it & 3);
   k_solve<<<1, 64, 0, st>>>(c->d_state, sums_device ? sums_device : c->d_sums, p.metric,
     c->origin[0], c->origin[1], c->origin[2], p.check_mean_distance, p.max_mean_distance,
-    c->d_counters, c->d_rec + slot);
+    c->d_counters, c->d_rec + slot, ++c->rec_seq);
   LAUNCHCHK();
-  HIPCHK(hipEventRecord(c->ev_rec[slot], st));
+  c->slot_seq[slot] = c->rec_seq;
   c->pass_local[slot] = c->last_local;
   c->run_it++;
   return ICPX_OK;
@@ -1839,13 +1915,15 @@ extern "C" int icpx_run(icpx_ctx* c, const icpx_params* p, double T_out[16], int
   {
     // one rank: nothing leaves the device until the loop is over
     rc = icpx_run_begin(c, p);
+    const bool fuse = !rc && c->nq > 0; // (an empty shard has no reduction to ride on)
     for (int it = 0; it < p->max_iterations && !rc; it++)
     {
       int done = 0;
-      rc = icpx_run_enqueue(c, nullptr, &done);
+      rc = run_enqueue_impl(c, nullptr, &done, fuse);
       if (rc || done)
         break;
-      rc = icpx_run_update(c, nullptr);
+      if (!fuse)
+        rc = icpx_run_update(c, nullptr);
     }
     if (rc)
     {

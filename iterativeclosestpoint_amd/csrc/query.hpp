@@ -489,14 +489,14 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))
 // depends only on the number of blocks, so results repeat run to run.
 // cert_mode says what the pass did to the shortcut's certificates: 1 brought them up to
 // date for the transform T (recorded in cert_T), 0 left them behind (cert_ok is cleared).
-__global__ __launch_bounds__(64) void k_reduce_partials(
+__device__ __forceinline__ bool reduce_partials_body(
   const double* __restrict__ partials, int nblocks, double* __restrict__ sums,
   const int32_t* __restrict__ stop, uint32_t* __restrict__ counters, double* __restrict__ stat,
   const double* __restrict__ T, double* __restrict__ cert_T, int32_t* __restrict__ cert_ok,
   int cert_mode)
 {
   if (stop && *stop)
-    return; // the pass did not run
+    return false; // the pass did not run
   const int i = blockIdx.x, l = threadIdx.x;
   if (cert_ok && i == 1)
   {
@@ -533,6 +533,17 @@ __global__ __launch_bounds__(64) void k_reduce_partials(
     if (stat)
       __threadfence_system();
   }
+  return true;
+}
+
+__global__ __launch_bounds__(64) void k_reduce_partials(
+  const double* __restrict__ partials, int nblocks, double* __restrict__ sums,
+  const int32_t* __restrict__ stop, uint32_t* __restrict__ counters, double* __restrict__ stat,
+  const double* __restrict__ T, double* __restrict__ cert_T, int32_t* __restrict__ cert_ok,
+  int cert_mode)
+{
+  (void)reduce_partials_body(partials, nblocks, sums, stop, counters, stat, T, cert_T, cert_ok,
+    cert_mode);
 }
 
 // Query set-up: gather the kept points (and normals) of the shard into Morton order.

@@ -28,6 +28,8 @@ struct RunRecord
   double mean, n;
   int32_t iters, status, done;
   uint32_t fallback;
+  uint32_t seq; // the solve's serial number, stored after the rest: the host waits for it
+  uint32_t pad_;
 };
 // One iteration's solve and transform update in a single GPU thread: the body of the
 // loop in vtkICP::InternalUpdate after the correspondence filter (ICP/vtkICP.cxx:218-245).
@@ -65,8 +67,9 @@ __device__ inline void solve_step(RunState* s, const double* __restrict__ sums, 
 }
 
 // The iteration's record for the host: written straight to pinned host memory, where the
-// host reads it behind an event two iterations later.
-__device__ inline void publish_record(const RunState* s, RunRecord* rec)
+// host finds it two iterations later by its serial number (no event, hence no marker in
+// the queue between iterations).
+__device__ inline void publish_record(const RunState* s, RunRecord* rec, uint32_t seq)
 {
   rec->mean = s->mean;
   rec->n = s->n;
@@ -74,6 +77,8 @@ __device__ inline void publish_record(const RunState* s, RunRecord* rec)
   rec->status = s->status;
   rec->done = s->done;
   rec->fallback = s->fallback;
+  __threadfence_system();
+  *reinterpret_cast<volatile uint32_t*>(&rec->seq) = seq;
   __threadfence_system();
 }
 

@@ -117,6 +117,10 @@ class ShardedICP:
         assert self.sums_dev is not None, "run_device needs use_device_allreduce=True"
         multi = dist.is_available() and dist.is_initialized() and \
             (dist.get_world_size(self.group) > 1 or force_collective)
+        if not multi:
+            # one rank: the library's own loop (the solve rides on the reduction's launch)
+            with torch.cuda.stream(self.stream):
+                return self.ctx.run(params)
         ptr = self.sums_dev.data_ptr()
         self.ctx.run_begin(params)
         with torch.cuda.stream(self.stream):

@@ -201,7 +201,8 @@ class Context:
         _chk(load().icpx_reset_hints(self._h))
 
     def set_timing(self, enable=True):
-        _chk(load().icpx_set_timing(self._h, int(bool(enable))))
+        """True/1: events around the search and the finalize kernels; 2: the search only."""
+        _chk(load().icpx_set_timing(self._h, int(enable)))
 
     def get_timing(self):
         """(search_ms, search_launches, finalize_ms, finalize_launches) since set_timing."""
