@@ -203,6 +203,7 @@ struct icpx_ctx
   int bad_streak = 0;    // consecutive passes it served too few queries while the residual was large
   int use_cert = 1;      // the shortcut keeps certificates (icpx_set_local(2) turns them off)
   int holdoff_len = 8;   // length of the next suspension: doubles each time one is called for
+  bool after_cold = false; // the last pass was a cold one
   bool probation = false; // back from a suspension: one more bad pass suspends it again
   bool last_local = false;   // the pass enqueued last tried the shortcut
   bool stat_local = false;   // ... and so did the pass whose figures are pending in h_stat
@@ -1298,7 +1299,19 @@ static int prepare_local(icpx_ctx* c, bool* use)
   if (!c->use_local || c->nbr_state < 0)
     return ICPX_OK;
   if (!c->hint_valid)
+  {
+    c->after_cold = true;
     return ICPX_OK; // a cold pass: a walk from the Morton seed settles too few queries to pay
+  }
+  if (c->after_cold)
+  {
+    // the pass after a cold one: the first step of a registration is its largest, last
+    // pass's winners are far from this pass's, and a whole pass of the tree kernel (which
+    // re-seeds such queries) is cheaper than a long walk plus the tree for what is left
+    c->after_cold = false;
+    if (c->persistent >= 3 && c->nq * 4 >= c->nt)
+      return ICPX_OK;
+  }
   if (c->stat_pending && hipEventQuery(c->ev_stat) == hipSuccess)
   {
     c->stat_pending = false;

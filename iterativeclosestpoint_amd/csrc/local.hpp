@@ -252,6 +252,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   // the stop flag: a pass that lets most queries through on their certificates is only as
   // long as its chain of dependent reads
   Xf T, Tc;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t q = (int64_t)blockIdx.x * 256 + tid;
+  const bool active = q < a.nq;
+  const int64_t qc = active ? q : 0;
+  const float p3[3] = { a.qpos[3 * qc], a.qpos[3 * qc + 1], a.qpos[3 * qc + 2] };
+  const float slack0 = la.cert ? la.cert[qc] : 0.f;
   const int32_t stopv = a.T.stop ? *a.T.stop : 0;
   int32_t okv = 0;
 #pragma unroll
@@ -278,10 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   __shared__ int32_t pendq[LOCAL_PEND][256];
   __shared__ uint32_t wcount[4];
   __shared__ uint32_t bbase;
-  const int tid = threadIdx.x, lane = tid & 63;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int64_t q = (int64_t)blockIdx.x * 256 + tid;
-  const bool active = q < a.nq;
 
   d3 x = mk(0.0, 0.0, 0.0);
   float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f;
@@ -309,8 +312,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   uint32_t e = 0, eend = 0;
   if (active)
   {
-    const float slack = cert_on ? la.cert[q] : 0.f; // (requested together with the point)
-    x = xform(T, a.qpos + 3 * q);
+    const float slack = cert_on ? slack0 : 0.f;
+    x = xform(T, p3);
     xf = (float)x.x;
     yf = (float)x.y;
     zf = (float)x.z;
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
       if (slack > 0.f)
       {
         // the move since the certificate was last brought up to date
-        const d3 xp = xform(Tc, a.qpos + 3 * q);
+        const d3 xp = xform(Tc, p3);
         const double mx = x.x - xp.x, my = x.y - xp.y, mz = x.z - xp.z;
         const float m2 = __double2float_ru(mx * mx + my * my + mz * mz);
         const float mv = __builtin_amdgcn_sqrtf(m2) * 1.000001f;

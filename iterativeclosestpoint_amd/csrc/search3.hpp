@@ -1189,10 +1189,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
       tau = 1e-9 * (double)smax;
       tauf = 1.0000001e-9f * smax;
       int32_t hs = a.use_hint ? a.hint[q] : -1;
-      if (hs < 0 && a.tcodes)
+      // last pass's winner is a poor start when the pose has moved by many triangle widths
+      // since (its centroid is then several of its radii away): such a query is seeded
+      // like a cold one, if that is nearer
+      float qbest = INFINITY;
+      bool stale = false;
+      if (hs >= 0)
       {
-        // cold start: of the few triangles around the query's place on the Morton curve,
-        // the one with the nearest centroid gives the first bound
+        const float4 rb = a.tpre[2 * (int64_t)hs + 1];
+        const float vx = xf - rb.x, vy = yf - rb.y, vz = zf - rb.z;
+        qbest = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
+        stale = qbest > 16.f * rb.w * rb.w;
+      }
+      if ((hs < 0 || stale) && a.tcodes)
+      {
+        // of the few triangles around the query's place on the Morton curve, the one with
+        // the nearest centroid gives the first bound
         const uint64_t code = morton63(xf, yf, zf, a.box.lo, a.box.inv);
         int64_t lo = 0, hi = a.nt; // first position with tcodes[pos] >= code
         while (lo < hi)
@@ -1203,7 +1215,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
           else
             hi = mid;
         }
-        float qbest = INFINITY;
 #pragma unroll
         for (int t = -SEEDW / 2; t < SEEDW / 2; t++)
         {
