@@ -1179,10 +1179,12 @@ static int ensure_bin(icpx_ctx* c, int L)
 }
 
 template <int L>
-static void launch_search3(
-  const Search3Args& a, unsigned grid, unsigned pgrid, unsigned wgrid, int mode, hipStream_t st)
+static void launch_search3(const Search3Args& a, unsigned grid, unsigned pgrid, unsigned wgrid,
+  int mode, const Search2Args* wide, hipStream_t st)
 {
-  if (mode == 3)
+  if (wide && pgrid && mode == 1)
+    k_fallback<L><<<pgrid, 256, 0, st>>>(a, *wide);
+  else if (mode == 3)
     k_search3w<L><<<wgrid, 64, 0, st>>>(a);
   else if (pgrid && mode == 2)
     k_search3q<L><<<pgrid, 256, 0, st>>>(a);
@@ -1268,6 +1270,8 @@ static int ensure_lists(icpx_ctx* c)
     eps = std::fmax(0.5 * eps, floor_eps);
   }
   c->nbr_state = c->nbr_eps > 0.f ? 1 : -1;
+  if (c->nbr_state == 1)
+    (void)ensure_heap(c, 64); // for short lists of leftovers (k_fallback); optional
   return ICPX_OK;
 }
 
@@ -1424,12 +1428,31 @@ static int run_search3(icpx_ctx* c)
   int mode = c->persistent;
   if (mode == 4)
     mode = (!use_local && c->nq * 4 >= c->nt) ? 3 : 1;
+  // the shortcut's leftovers: a short list goes one wavefront per query over the 64-ary tree
+  Search2Args wide;
+  const Search2Args* widep = nullptr;
+  if (use_local && mode == 1 && c->heaps[4].built)
+  {
+    const Heap& h = c->heaps[4];
+    wide.qpos = c->d_qpos;
+    wide.nq = c->nq;
+    wide.T = a.T;
+    wide.nodes = h.nodes;
+    wide.tree = h.t;
+    wide.tverts = c->d_tverts;
+    wide.tid = c->d_tid;
+    wide.nt = c->nt;
+    wide.hint = c->d_hint;
+    wide.use_hint = 1;
+    wide.scene_max = c->scene_max;
+    widep = &wide;
+  }
   if (L == 1)
-    launch_search3<1>(a, grid, pgrid, wgrid, mode, st);
+    launch_search3<1>(a, grid, pgrid, wgrid, mode, widep, st);
   else if (L == 2)
-    launch_search3<2>(a, grid, pgrid, wgrid, mode, st);
+    launch_search3<2>(a, grid, pgrid, wgrid, mode, widep, st);
   else
-    launch_search3<4>(a, grid, pgrid, wgrid, mode, st);
+    launch_search3<4>(a, grid, pgrid, wgrid, mode, widep, st);
   LAUNCHCHK();
   c->hint_valid = true;
   return ICPX_OK;

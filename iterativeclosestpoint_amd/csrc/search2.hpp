@@ -315,12 +315,13 @@ struct Search2Cfg
   static constexpr int GPB = 256 / G;
 };
 
+// The search of one query by its group of G lanes (group g of the block, lane j of the
+// group).  Groups synchronise only within their wavefront, so wavefronts of a block may
+// call this different numbers of times.
 template <int G>
-__global__ __launch_bounds__(256) void k_search2(Search2Args a)
+__device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, int64_t q,
+  bool active)
 {
-  Xf T;
-  if (!load_xf(a.T, T))
-    return; // the registration this pass belongs to has already stopped
   using Cfg = Search2Cfg<G>;
   __shared__ unsigned long long stack[Cfg::GPB][Cfg::STACK];
   __shared__ int32_t ring[Cfg::GPB][Cfg::RING];
@@ -328,8 +329,6 @@ __global__ __launch_bounds__(256) void k_search2(Search2Args a)
   const int g = tid / G, j = tid % G;
   const int lane = tid & 63;
   const int gbase = lane & ~(G - 1);
-  const int64_t q = (int64_t)blockIdx.x * Cfg::GPB + g;
-  const bool active = q < a.nq;
   const uint32_t first_leaf = (uint32_t)a.tree.first_leaf;
   constexpr uint32_t GM = (G >= 32) ? 0xffffffffu : ((1u << (G & 31)) - 1u); // a group's lanes
 
@@ -505,6 +504,16 @@ __global__ __launch_bounds__(256) void k_search2(Search2Args a)
     if (j == 0)
       a.hint[q] = win;
   }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_search2(Search2Args a)
+{
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
+  const int64_t q = (int64_t)blockIdx.x * Search2Cfg<G>::GPB + threadIdx.x / G;
+  search2_body<G>(a, T, q, q < a.nq);
 }
 
 } // namespace icpx

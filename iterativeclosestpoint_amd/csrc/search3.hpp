@@ -477,11 +477,8 @@ __device__ unsigned long long g_stats[8];
 #endif
 
 template <int L>
-__global__ __launch_bounds__(256) void k_search3p(Search3Args a)
+__device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
 {
-  Xf T;
-  if (!load_xf(a.T, T))
-    return; // the registration this pass belongs to has already stopped
   __shared__ int32_t ring[RING3][256];
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -719,6 +716,43 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
   atomicAdd(&g_stats[4], st_4);
   atomicAdd(&g_stats[5], st_5);
 #endif
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void k_search3p(Search3Args a)
+{
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
+  search3p_body<L>(a, T);
+}
+
+// What the shortcut left over, by the size of the list.  A lane that walks the tree alone
+// takes ~150 us for one query whatever the number of queries, so a short list (a few
+// stragglers of a converged pass) is served one WAVEFRONT per query instead, over the
+// 64-ary tree of search2.hpp (a few steps of 64 box tests each); a long list by the
+// pooled lanes.  Same results either way.
+constexpr uint32_t FALLBACK_SMALL = 16384;
+
+template <int L>
+__global__ __launch_bounds__(256) void k_fallback(Search3Args a, Search2Args w)
+{
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
+  const uint32_t total = a.counters[3];
+  if (total > FALLBACK_SMALL)
+  {
+    search3p_body<L>(a, T);
+    return;
+  }
+  const int wave = threadIdx.x >> 6;
+  for (uint32_t base = blockIdx.x * 4u; base < total; base += gridDim.x * 4u)
+  {
+    const uint32_t idx = base + (uint32_t)wave;
+    const bool active = idx < total;
+    search2_body<64>(w, T, active ? (int64_t)a.qlist[idx] : 0, active);
+  }
 }
 
 // The pooled search with cheap bounds on both sides.  At a leaf every triangle yields, from
