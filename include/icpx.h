@@ -245,7 +245,8 @@ extern "C"
    * query); 4: {shortcut passes, tree-only passes, neighbour-list builds, list radius x
    * 1e9, list entries} (5 x int64); 5: the shortcut's certificates (float per query of
    * this shard: how far the query may still move before its winner is looked at again,
-   * 0 = none). */
+   * 0 = none); 6: the library's query order (int32 per query: position -> kept index
+   * within the shard; arrays 0 and 5 are in this order). */
   int icpx_debug_dump(icpx_ctx* ctx, int what, void* out, int64_t count);
 
   /* Forget the winners of the previous search pass.  A pass normally starts each

@@ -670,6 +670,11 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
     src = c->d_cert;
     bytes = sizeof(float) * (size_t)std::min<int64_t>(count, c->nq);
   }
+  else if (what == 6 && c->d_qk)
+  {
+    src = c->d_qk;
+    bytes = sizeof(int32_t) * (size_t)std::min<int64_t>(count, c->nq);
+  }
   if (!src)
     return fail(ICPX_E_INVALID, "nothing to dump");
   HIPCHK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));

@@ -185,6 +185,12 @@ class Context:
         _chk(load().icpx_debug_dump(self._h, 5, _p(v), int(n)))
         return v
 
+    def debug_query_order(self, n):
+        """Position in the library's query order -> kept index within the shard."""
+        v = np.zeros(int(n), np.int32)
+        _chk(load().icpx_debug_dump(self._h, 6, _p(v), int(n)))
+        return v
+
     def set_persistent(self, enable=True):
         _chk(load().icpx_set_persistent(self._h, int(enable)))
 

@@ -666,7 +666,8 @@ def test_shortcut_on_triangle_soup(icpx, synth, oracle, seed):
     q[:50] = fan_c + np.array([0, 0, 1.0]) * np.linspace(1e-6, 0.2, 50)[:, None]  # above the fan
     q = q.astype(np.float32)
     ctxs = []
-    for local in (True, False):
+    modes = (1, 0, 2)  # shortcut with certificates, tree only, shortcut without certificates
+    for local in modes:
         c_ = icpx.Context(0)
         c_.set_group_width(1)
         c_.set_local(local)
@@ -675,14 +676,19 @@ def test_shortcut_on_triangle_soup(icpx, synth, oracle, seed):
         ctxs.append(c_)
     Ts = [np.eye(4), np.eye(4), synth.rigid(rz=0.02, t=(1e-4, 0, 0)), synth.rigid(rz=0.02, t=(1e-4, 0, 0)),
           synth.rigid(rx=0.5, t=(0.003, -0.002, 0.001)), np.eye(4), np.eye(4)]
+    # then a slow drift, the regime in which certificates let winners stand: here they must
+    # do so only where a search would agree, on slivers, duplicates and the fan as well
+    for k, m in enumerate((1e-9, 1e-8, 1e-7, 3e-7, 1e-6, 1e-8, 1e-5, 1e-8, 1e-4, 1e-8)):
+        Ts.append(synth.rigid(rx=10 * m, ry=-7 * m, t=(m, 0.5 * m, -m)) @ Ts[-1])
     for i, T in enumerate(Ts):
         ref = mesh.correspond(q, T=T, step=1, max_dist=10.0, grid=True)
-        for c_ in ctxs:
+        for c_, local in zip(ctxs, modes):
             if i in (1, 5):
-                c_.set_local(c_ is ctxs[0])  # (restarts the shortcut's policy after far passes)
+                c_.set_local(local)  # (restarts the shortcut's policy after far passes)
             check_rows(c_.correspond(T, step=1, max_dist=10.0), ref)
             c_.accumulate(1, T, step=1, max_dist=10.0)  # a second hinted pass at the same pose
-    assert ctxs[0].debug_stats()["local_passes"] >= 6
+    assert ctxs[0].debug_stats()["local_passes"] >= 20
+    assert (ctxs[0].debug_certificates(nq) > 0).mean() > 0.3
 
 
 def test_certificates_change_nothing(icpx, synth, oracle):
@@ -719,6 +725,65 @@ def test_certificates_change_nothing(icpx, synth, oracle):
         kept.append(float((ctxs[0].debug_certificates(len(src)) > 0).mean()))
     assert ctxs[0].debug_stats()["local_passes"] >= 20
     assert min(kept[2:8]) > 0.9 and kept[-1] > 0.9  # most queries hold a certificate
+
+
+def _point_triangle_dist(q, P):
+    """Distances from points q (n,3) to triangles P (m,3,3), all pairs, float64 (Ericson)."""
+    a, b, c = P[None, :, 0], P[None, :, 1], P[None, :, 2]
+    p = q[:, None, :]
+    ab, ac, ap = b - a, c - a, p - a
+    d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
+    bp = p - b
+    d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
+    cp = p - c
+    d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
+    va, vb, vc = d3 * d6 - d5 * d4, d5 * d2 - d1 * d6, d1 * d4 - d3 * d2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        den = va + vb + vc
+        v, w = vb / den, vc / den
+        pt = a + ab * v[..., None] + ac * w[..., None]
+        t_ab = (d1 / (d1 - d3))[..., None]
+        t_ac = (d2 / (d2 - d6))[..., None]
+        t_bc = ((d4 - d3) / ((d4 - d3) + (d5 - d6)))[..., None]
+    pt = np.where(((va <= 0) & (d4 - d3 >= 0) & (d5 - d6 >= 0))[..., None], b + (c - b) * t_bc, pt)
+    pt = np.where(((vb <= 0) & (d2 >= 0) & (d6 <= 0))[..., None], a + ac * t_ac, pt)
+    pt = np.where(((d6 >= 0) & (d5 <= d6))[..., None], c + 0 * p, pt)
+    pt = np.where(((vc <= 0) & (d1 >= 0) & (d3 <= 0))[..., None], a + ab * t_ab, pt)
+    pt = np.where(((d3 >= 0) & (d4 <= d3))[..., None], b + 0 * p, pt)
+    pt = np.where(((d1 <= 0) & (d2 <= 0))[..., None], a + 0 * p, pt)
+    return np.sqrt(((p - pt) ** 2).sum(-1))
+
+
+def test_certificate_is_below_the_true_gap(icpx, synth):
+    """The slack a query is given never exceeds what it certifies: the distance of the
+    second nearest triangle less that of the nearest (all pairs, brute force in numpy)."""
+    xyz, tri = synth.bumpy_torus(48, 24)
+    pts, f, fn = synth.sample_surface(xyz, tri, 40_000, seed=33)
+    off = np.stack([synth.gaussian(8, 90 + 2 * k, len(pts)) for k in range(3)], -1)
+    scale = 10.0 ** (-8 + 6 * synth.u01(8, 97, len(pts)))
+    src = (pts.astype(np.float64) + off * scale[:, None]).astype(np.float32)
+    ctx = icpx.Context(0)
+    ctx.set_group_width(1)
+    ctx.set_target(xyz, tri)
+    ctx.set_source(src)
+    T = synth.rigid(rz=0.01, t=(1e-4, 0, 0))
+    for _ in range(3):
+        ctx.accumulate(1, T, step=1, max_dist=10.0)  # cold, tree, then the shortcut: certificates
+    T2 = synth.rigid(rx=2e-6, t=(0, 1e-7, 0)) @ T
+    ctx.accumulate(1, T2, step=1, max_dist=10.0)     # a small move: slacks shrink by twice it
+    cert = ctx.debug_certificates(len(src))
+    order = ctx.debug_query_order(len(src))
+    assert (cert > 0).mean() > 0.9
+    P = xyz[tri].astype(np.float64)
+    x = src.astype(np.float64) @ T2[:3, :3].T + T2[:3, 3]  # as the kernels transform: in fp64
+    worst = 0.0
+    for k0 in range(0, 4000, 500):  # a sample of the queries, in chunks
+        pos = np.arange(k0 * 10, k0 * 10 + 500)
+        d = np.sort(_point_triangle_dist(x[order[pos]], P), axis=1)
+        gap = d[:, 1] - d[:, 0]
+        assert np.all(cert[pos] <= gap + 1e-12), "a certificate exceeds the true gap"
+        worst = max(worst, float((cert[pos] / np.maximum(gap, 1e-300)).max()))
+    assert worst <= 1.0 + 1e-9
 
 
 def _sharded_rank(rank, world, port, metric, out):
