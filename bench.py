@@ -74,9 +74,16 @@ def main():
                     help="process-group backend (gloo + --one-device rehearses N ranks on one GPU)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="development: one rank, but through the multi-rank loop with its all-reduce")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="development: leave out the HIP events around the search kernels")
     args = ap.parse_args()
+
+    # Only the result line may reach stdout: libraries underneath (RCCL's version banner,
+    # gloo's connection notes) write there too, so everything else is sent to stderr.
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -94,8 +101,9 @@ def main():
     if args.one_device:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local))
@@ -126,7 +134,7 @@ def main():
         if iters <= 0:
             return np.eye(4), 0, 0.0
         params.max_iterations = iters
-        T, it, md, status = sh.run_device(params)
+        T, it, md, status = sh.run_device(params, force_collective=args.force_collective)
         return T, it, md
 
     def fence():
@@ -225,8 +233,9 @@ def main():
                           "source points of the same workload, bucket-grid locator restatement of "
                           "the vtkSMPTools path, %.1f s" % (nsample, dt),
             }
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or args.force_collective:
         dist.destroy_process_group()
 
 
