@@ -122,6 +122,18 @@ extern "C"
     double min_dot, int use_source_normals, float* origin, float* origin_normal, float* closest,
     float* normal, int32_t* cell, double* dist, int64_t* src_index, int64_t* n_out);
 
+  /* The same rows in double precision: what the filter produces with OutputPrecision =
+   * DOUBLE_PRECISION, where the reference runs its functor with double output arrays
+   * (ICP/vtkPolyDataCorrespondenceFilter.cxx:481-483, 519-531): the transformed point,
+   * the closest point and the locator's normal as the doubles they were computed in.
+   * That path has no origin normals and no normal-compatibility test
+   * (Functor, not NormalsFunctor, :525).  The normal is the fp64 face normal, or the
+   * edge / angle-weighted vertex sum made from the fp64 face normals
+   * (ICP/vtkImplicitPolyDataDistance2.cxx:397-517). */
+  int icpx_correspond_f64(icpx_ctx* ctx, const double T[16], int64_t step, double max_dist,
+    double* origin, double* closest, double* normal, int32_t* cell, double* dist,
+    int64_t* src_index, int64_t* n_out);
+
   /* Host-side solve of one iteration from (all-reduced) sums: 3x3 SVD for
    * point-to-point (ICP/icp/point2point.cxx:45-58), 6x6 LDL^T + Euler XYZ for
    * point-to-plane (ICP/icp/point2plane.cxx:88-106), 6x6 LDL^T + Rodrigues

@@ -12,6 +12,7 @@
 #include "local.hpp"
 #include "state.hpp"
 #include "tables.hpp"
+#include "rows64.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -173,6 +174,10 @@ struct icpx_ctx
   float* d_cert = nullptr;      // per query: the shortcut's certificate (see local.hpp)
   uint32_t* d_ticket = nullptr; // k_reduce_solve's count of finished blocks (zero between launches)
   float *d_fn = nullptr, *d_en = nullptr, *d_vn = nullptr;
+  // kept for the double-precision rows: fp64 face normals and the links (cells per point)
+  double* d_fn64 = nullptr;
+  uint32_t* d_voff = nullptr;
+  int32_t* d_vcell = nullptr;
   Box3 box;
   double origin[3] = { 0, 0, 0 };
   Tree trees[5];  // exhaustive-exact kernel's level-array trees
@@ -261,6 +266,10 @@ struct icpx_ctx
   int32_t* r_cell = nullptr;
   double* r_dist = nullptr;
   uint32_t *r_flag = nullptr, *r_pos = nullptr, *r_scan = nullptr;
+  // the same in double precision (icpx_correspond_f64), allocated on first use
+  double *r64_origin = nullptr, *r64_closest = nullptr, *r64_normal = nullptr, *r64_dist = nullptr;
+  double *c64_origin = nullptr, *c64_closest = nullptr, *c64_normal = nullptr, *c64_dist = nullptr;
+  int64_t rows64_cap = 0;
   float *c_origin = nullptr, *c_onormal = nullptr, *c_closest = nullptr, *c_normal = nullptr;
   int32_t* c_cell = nullptr;
   double* c_dist = nullptr;
@@ -394,6 +403,9 @@ static void free_target(icpx_ctx* c)
   dev_free(&c->d_tcodes);
   dev_free(&c->d_tpre);
   dev_free(&c->d_fn);
+  dev_free(&c->d_fn64);
+  dev_free(&c->d_voff);
+  dev_free(&c->d_vcell);
   dev_free(&c->d_en);
   dev_free(&c->d_vn);
   for (auto& t : c->trees)
@@ -456,6 +468,15 @@ static void free_rows(icpx_ctx* c)
   dev_free(&c->c_dist);
   dev_free(&c->c_index);
   c->rows_cap = 0;
+  dev_free(&c->r64_origin);
+  dev_free(&c->r64_closest);
+  dev_free(&c->r64_normal);
+  dev_free(&c->r64_dist);
+  dev_free(&c->c64_origin);
+  dev_free(&c->c64_closest);
+  dev_free(&c->c64_normal);
+  dev_free(&c->c64_dist);
+  c->rows64_cap = 0;
 }
 
 extern "C" const char* icpx_last_error(void)
@@ -957,6 +978,16 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   e = hipGetLastError();
   if (e == hipSuccess)
     e = hipStreamSynchronize(st);
+  if (e == hipSuccess)
+  {
+    // the fp64 face normals and the links stay: double-precision rows are made from them
+    c->d_fn64 = fn64;
+    c->d_voff = voff;
+    c->d_vcell = vcell;
+    fn64 = nullptr;
+    voff = nullptr;
+    vcell = nullptr;
+  }
   drop_tab();
   if (e != hipSuccess)
     return fail(ICPX_E_HIP, "normal tables failed: %s", hipGetErrorString(e));
@@ -1788,6 +1819,130 @@ extern "C" int icpx_correspond(icpx_ctx* c, const double T[16], int64_t step, do
   HIPCHK(back(normal, c->c_normal, sizeof(float) * 3 * n));
   HIPCHK(back(cell, c->c_cell, sizeof(int32_t) * n));
   HIPCHK(back(dist, c->c_dist, sizeof(double) * n));
+  HIPCHK(back(src_index, c->c_index, sizeof(int64_t) * n));
+  HIPCHK(hipStreamSynchronize(st));
+  *n_out = n;
+  return ICPX_OK;
+}
+
+// The rows in double precision: vtkPolyDataCorrespondenceFilter with OutputPrecision =
+// DOUBLE_PRECISION (ICP/vtkPolyDataCorrespondenceFilter.cxx:519-531).
+extern "C" int icpx_correspond_f64(icpx_ctx* c, const double T[16], int64_t step, double max_dist,
+  double* origin, double* closest, double* normal, int32_t* cell, double* dist,
+  int64_t* src_index, int64_t* n_out)
+{
+  int rc = check_call(c, T, 0, 0);
+  if (rc)
+    return rc;
+  if (!n_out)
+    return fail(ICPX_E_INVALID, "icpx_correspond_f64: n_out is null");
+  *n_out = 0;
+  if (!c->d_fn64 || !c->d_voff || !c->d_vcell)
+    return fail(ICPX_E_INVALID, "Can't execute with nullptr or empty target");
+  HIPCHK(hipSetDevice(c->device));
+  rc = prepare_queries(c, step);
+  if (rc)
+    return rc;
+  const int64_t nq = c->nq;
+  if (nq == 0)
+    return ICPX_OK;
+  hipStream_t st = c->stream;
+  if (nq > c->rows_cap)
+  {
+    // (the flag / position / cell / index arrays are shared with the float rows)
+    free_rows(c);
+    ALLOC(c->r_origin, 3 * nq);
+    ALLOC(c->r_onormal, 3 * nq);
+    ALLOC(c->r_closest, 3 * nq);
+    ALLOC(c->r_normal, 3 * nq);
+    ALLOC(c->r_cell, nq);
+    ALLOC(c->r_dist, nq);
+    ALLOC(c->r_flag, nq + 1);
+    ALLOC(c->r_pos, nq + 1);
+    ALLOC(c->r_scan, scan_scratch_words(nq + 1));
+    ALLOC(c->c_origin, 3 * nq);
+    ALLOC(c->c_onormal, 3 * nq);
+    ALLOC(c->c_closest, 3 * nq);
+    ALLOC(c->c_normal, 3 * nq);
+    ALLOC(c->c_cell, nq);
+    ALLOC(c->c_dist, nq);
+    ALLOC(c->c_index, nq);
+    c->rows_cap = nq;
+  }
+  if (nq > c->rows64_cap)
+  {
+    ALLOC(c->r64_origin, 3 * nq);
+    ALLOC(c->r64_closest, 3 * nq);
+    ALLOC(c->r64_normal, 3 * nq);
+    ALLOC(c->r64_dist, nq);
+    ALLOC(c->c64_origin, 3 * nq);
+    ALLOC(c->c64_closest, 3 * nq);
+    ALLOC(c->c64_normal, 3 * nq);
+    ALLOC(c->c64_dist, nq);
+    c->rows64_cap = nq;
+  }
+  c->run_active = false;
+  rc = set_transform(c, T, 0);
+  if (!rc)
+    rc = run_search(c);
+  if (rc)
+    return rc;
+  k_cert_mark<<<1, 64, 0, st>>>(c->d_state, (c->last_local && c->use_cert) ? 1 : 0);
+  Rows64Args a;
+  a.qpos = c->d_qpos;
+  a.qk = c->d_qk;
+  a.nq = nq;
+  a.T = xf_ref(c);
+  a.tverts = c->d_tverts;
+  a.tid = c->d_tid;
+  a.tri = c->d_tri;
+  a.xyz = c->d_xyz;
+  a.fn64 = c->d_fn64;
+  a.voff = c->d_voff;
+  a.vcell = c->d_vcell;
+  a.hint = c->d_hint;
+  a.max_dist = max_dist;
+  a.o_origin = c->r64_origin;
+  a.o_closest = c->r64_closest;
+  a.o_normal = c->r64_normal;
+  a.o_dist = c->r64_dist;
+  a.o_cell = c->r_cell;
+  a.o_flag = c->r_flag;
+  HIPCHK(hipMemsetAsync(c->r_flag + nq, 0, sizeof(uint32_t), st));
+  k_rows64<<<nblk(nq, 256), 256, 0, st>>>(a);
+  exclusive_scan(c->r_flag, c->r_pos, nq + 1, c->r_scan, st);
+  Compact64Args ca;
+  ca.nq = nq;
+  ca.k0 = c->k0;
+  ca.step = step;
+  ca.flag = c->r_flag;
+  ca.pos = c->r_pos;
+  ca.origin = c->r64_origin;
+  ca.closest = c->r64_closest;
+  ca.normal = c->r64_normal;
+  ca.dist = c->r64_dist;
+  ca.cell = c->r_cell;
+  ca.d_origin = c->c64_origin;
+  ca.d_closest = c->c64_closest;
+  ca.d_normal = c->c64_normal;
+  ca.d_dist = c->c64_dist;
+  ca.d_cell = c->c_cell;
+  ca.d_index = c->c_index;
+  k_compact_rows64<<<nblk(nq, 256), 256, 0, st>>>(ca);
+  LAUNCHCHK();
+  uint32_t n = 0;
+  HIPCHK(hipMemcpyAsync(&n, c->r_pos + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  auto back = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    if (!dst || !bytes)
+      return hipSuccess;
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+  };
+  HIPCHK(back(origin, c->c64_origin, sizeof(double) * 3 * n));
+  HIPCHK(back(closest, c->c64_closest, sizeof(double) * 3 * n));
+  HIPCHK(back(normal, c->c64_normal, sizeof(double) * 3 * n));
+  HIPCHK(back(cell, c->c_cell, sizeof(int32_t) * n));
+  HIPCHK(back(dist, c->c64_dist, sizeof(double) * n));
   HIPCHK(back(src_index, c->c_index, sizeof(int64_t) * n));
   HIPCHK(hipStreamSynchronize(st));
   *n_out = n;

@@ -87,13 +87,10 @@ __global__ void k_sort_links(
 }
 
 // Angle-weighted pseudo-normal of every point (:475-516).
-__global__ void k_vertex_normals(const float* __restrict__ xyz, const int32_t* __restrict__ tri,
-  const uint32_t* __restrict__ voff, const int32_t* __restrict__ vcell,
-  const double* __restrict__ fn64, int64_t nv, float* __restrict__ vn32)
+__device__ __forceinline__ d3 vertex_normal64(const float* __restrict__ xyz,
+  const int32_t* __restrict__ tri, const uint32_t* __restrict__ voff,
+  const int32_t* __restrict__ vcell, const double* __restrict__ fn64, int64_t v)
 {
-  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= nv)
-    return;
   const int32_t a = (int32_t)v;
   d3 pa = load_vtx(xyz, a);
   d3 aw = mk(0.0, 0.0, 0.0);
@@ -117,6 +114,17 @@ __global__ void k_vertex_normals(const float* __restrict__ xyz, const int32_t* _
     aw.z += alpha * fn64[3 * c + 2];
   }
   normalize(aw);
+  return aw;
+}
+
+__global__ void k_vertex_normals(const float* __restrict__ xyz, const int32_t* __restrict__ tri,
+  const uint32_t* __restrict__ voff, const int32_t* __restrict__ vcell,
+  const double* __restrict__ fn64, int64_t nv, float* __restrict__ vn32)
+{
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv)
+    return;
+  const d3 aw = vertex_normal64(xyz, tri, voff, vcell, fn64, v);
   vn32[3 * v] = (float)aw.x;
   vn32[3 * v + 1] = (float)aw.y;
   vn32[3 * v + 2] = (float)aw.z;
@@ -125,15 +133,10 @@ __global__ void k_vertex_normals(const float* __restrict__ xyz, const int32_t* _
 // Edge pseudo-normal for every (cell, edge): edge e joins points (e+1)%3 and
 // (e+2)%3 of the cell; all cells of the first point that also use the second
 // contribute, in link order (GetCellEdgeNeighbors with a bogus cell id, :433-450).
-__global__ void k_edge_normals(const int32_t* __restrict__ tri,
+__device__ __forceinline__ d3 edge_normal64(const int32_t* __restrict__ tri,
   const uint32_t* __restrict__ voff, const int32_t* __restrict__ vcell,
-  const double* __restrict__ fn64, int64_t nt, float* __restrict__ en32)
+  const double* __restrict__ fn64, int64_t c, int e)
 {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * nt)
-    return;
-  int64_t c = i / 3;
-  int e = (int)(i % 3);
   int32_t a = tri[3 * c + (e + 1) % 3];
   int32_t b = tri[3 * c + (e + 2) % 3];
   d3 aw = mk(0.0, 0.0, 0.0);
@@ -152,6 +155,17 @@ __global__ void k_edge_normals(const int32_t* __restrict__ tri,
     }
   }
   normalize(aw);
+  return aw;
+}
+
+__global__ void k_edge_normals(const int32_t* __restrict__ tri,
+  const uint32_t* __restrict__ voff, const int32_t* __restrict__ vcell,
+  const double* __restrict__ fn64, int64_t nt, float* __restrict__ en32)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * nt)
+    return;
+  const d3 aw = edge_normal64(tri, voff, vcell, fn64, i / 3, (int)(i % 3));
   en32[3 * i] = (float)aw.x;
   en32[3 * i + 1] = (float)aw.y;
   en32[3 * i + 2] = (float)aw.z;

@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("ICPX_LIB") or os.path.join(_HERE, "libicpx.so")  # (I
 SYMBOLS = (
     "icpx_last_error", "icpx_device_count", "icpx_create", "icpx_destroy", "icpx_set_stream",
     "icpx_synchronize", "icpx_set_target", "icpx_set_source", "icpx_set_shard", "icpx_get_origin",
-    "icpx_accumulate", "icpx_correspond", "icpx_solve", "icpx_default_params",
+    "icpx_accumulate", "icpx_correspond", "icpx_correspond_f64", "icpx_solve", "icpx_default_params",
     "icpx_set_allreduce", "icpx_run", "icpx_last_build_seconds", "icpx_set_group_width",
     "icpx_reset_hints", "icpx_set_timing", "icpx_get_timing", "icpx_set_exhaustive",
     "icpx_set_leaf_size", "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local",
@@ -71,6 +71,7 @@ def load():
     lib.icpx_accumulate.argtypes = [vp, ci, vp, i64, dbl, dbl, ci, vp, vp]
     lib.icpx_correspond.argtypes = [vp, vp, i64, dbl, dbl, ci, vp, vp, vp, vp, vp, vp, vp,
                                     C.POINTER(i64)]
+    lib.icpx_correspond_f64.argtypes = [vp, vp, i64, dbl, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
     lib.icpx_solve.argtypes = [ci, vp, vp, vp, C.POINTER(i64), C.POINTER(dbl)]
     lib.icpx_default_params.argtypes = [C.POINTER(Params)]
     lib.icpx_default_params.restype = None
@@ -286,6 +287,22 @@ class Context:
             self._h, _p(T), step, float(max_dist), float(min_dot), int(bool(use_source_normals)),
             _p(out["origin"]), _p(out["origin_normal"]), _p(out["closest"]), _p(out["normal"]),
             _p(out["cell"]), _p(out["dist"]), _p(out["src_index"]), C.byref(n)))
+        return {k: v[:n.value] for k, v in out.items()}
+
+    def correspond_f64(self, T=None, step=1, max_dist=10.0):
+        """The filter's outputs in double precision (OutputPrecision = DOUBLE_PRECISION)."""
+        T = np.eye(4) if T is None else np.asarray(T, np.float64)
+        T = np.ascontiguousarray(T).reshape(16)
+        step = max(1, int(step))
+        nk = (self._np + step - 1) // step
+        out = dict(origin=np.zeros((nk, 3), np.float64), closest=np.zeros((nk, 3), np.float64),
+                   normal=np.zeros((nk, 3), np.float64), cell=np.zeros(nk, np.int32),
+                   dist=np.zeros(nk, np.float64), src_index=np.zeros(nk, np.int64))
+        n = C.c_int64(0)
+        _chk(load().icpx_correspond_f64(
+            self._h, _p(T), step, float(max_dist), _p(out["origin"]), _p(out["closest"]),
+            _p(out["normal"]), _p(out["cell"]), _p(out["dist"]), _p(out["src_index"]),
+            C.byref(n)))
         return {k: v[:n.value] for k, v in out.items()}
 
     def set_allreduce(self, fn):

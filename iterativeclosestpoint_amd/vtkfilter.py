@@ -12,8 +12,9 @@ direction.  The search itself is `icpx_correspond`.
 Two things differ from the reference as written, both where the reference reads memory it
 never wrote: landmark normals are the locator's (the reference self-assigns,
 .cxx:126-132) and MinNormalDot defaults to 0.0 and is tested against the source normal
-(.cxx:286, .h:66-71).  Double output precision is not implemented (rows are float, as
-vtkICP asks for them, ICP/vtkICP.cxx:38).
+(.cxx:286, .h:66-71).  With double output precision the rows come from
+`icpx_correspond_f64`; as in the reference (.cxx:519-531) that path has neither origin
+normals nor the normal test.
 """
 import sys
 
@@ -178,8 +179,7 @@ class vtkPolyDataCorrespondenceFilter:
             source, target = in1, in0
         if source._point_dtype != np.float32:
             return self._fail("We only support float input data")
-        if self.OutputPrecision == self.DOUBLE_PRECISION:
-            return self._fail("Double output precision is not implemented")
+        double = self.OutputPrecision == self.DOUBLE_PRECISION
         if target.GetNumberOfCells() == 0:
             return self._fail("No polygons to evaluate function!")
         sn = None
@@ -205,11 +205,16 @@ class vtkPolyDataCorrespondenceFilter:
 
         n = source.GetNumberOfPoints()
         step = n // self.MaximumNumberOfLandmarks if n > self.MaximumNumberOfLandmarks else 1
-        rows = self._ctx.correspond(self.Transform, step=step, max_dist=self.MaximumDistance,
-                                    min_dot=self.MinNormalDot,
-                                    use_source_normals=self.IncludeOriginNormals)
+        if double:
+            # Functor with double outputs (.cxx:525): no origin normals, no normal test
+            rows = self._ctx.correspond_f64(self.Transform, step=step,
+                                            max_dist=self.MaximumDistance)
+        else:
+            rows = self._ctx.correspond(self.Transform, step=step, max_dist=self.MaximumDistance,
+                                        min_dot=self.MinNormalDot,
+                                        use_source_normals=self.IncludeOriginNormals)
         out0 = vtkPolyData(rows["origin"])
-        if self.IncludeOriginNormals:
+        if self.IncludeOriginNormals and not double:
             out0.SetPointNormals(rows["origin_normal"])
         out1 = vtkPolyData(rows["closest"])
         out1.SetPointNormals(rows["normal"])

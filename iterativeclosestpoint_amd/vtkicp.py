@@ -51,8 +51,9 @@ class vtkPolyData:
         return len(self._polys)
 
     def SetPointNormals(self, n):
-        self._point_normals = None if n is None else np.ascontiguousarray(
-            n, np.float32).reshape(-1, 3)
+        # float, or double where the producer ran with double output precision
+        dt = np.float64 if n is not None and np.asarray(n).dtype == np.float64 else np.float32
+        self._point_normals = None if n is None else np.ascontiguousarray(n, dt).reshape(-1, 3)
 
     def GetPointNormals(self):
         return self._point_normals

@@ -779,6 +779,69 @@ int64_t orc_correspond(const orc_mesh* m, const float* src, int64_t np, const fl
   return n;
 }
 
+/* The filter with OutputPrecision = DOUBLE_PRECISION
+ * (ICP/vtkPolyDataCorrespondenceFilter.cxx:519-531): Functor with double outputs, i.e. the
+ * same loop (:87-137) storing the transformed point, the closest point and the locator's
+ * normal unrounded; no origin normals and no normal test on this path. */
+int64_t orc_correspond_f64(const orc_mesh* m, const float* src, int64_t np, const double T[16],
+  int64_t step, double max_dist, int use_grid, int nthreads, double* origin, double* closest,
+  double* normal, int32_t* cell, double* dist, int64_t* src_index)
+{
+  if (step < 1)
+    step = 1;
+  int64_t nk = (np + step - 1) / step;
+  char* ok = (char*)calloc((size_t)nk + 1, 1);
+  double* tmp = (double*)malloc(sizeof(double) * 10 * (size_t)(nk + 1));
+  int32_t* tc = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nk + 1));
+#ifdef _OPENMP
+  if (nthreads < 1)
+    nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads)
+#endif
+  for (int64_t k = 0; k < nk; k++)
+  {
+    int64_t i = k * step;
+    double x[3] = { (double)src[3 * i], (double)src[3 * i + 1], (double)src[3 * i + 2] };
+    double n[3], cp[3];
+    int64_t c;
+    int kd;
+    xform(T, x, x);
+    double sd = orc_closest_point_and_normal(m, x, use_grid, n, cp, &c, &kd);
+    ok[k] = (char)(fabs(sd) < max_dist && c >= 0);
+    for (int a = 0; a < 3; a++)
+    {
+      tmp[10 * k + a] = x[a];
+      tmp[10 * k + 3 + a] = cp[a];
+      tmp[10 * k + 6 + a] = n[a];
+    }
+    tmp[10 * k + 9] = fabs(sd);
+    tc[k] = (int32_t)c;
+  }
+  int64_t n = 0;
+  for (int64_t k = 0; k < nk; k++)
+  {
+    if (!ok[k])
+      continue;
+    for (int a = 0; a < 3; a++)
+    {
+      origin[3 * n + a] = tmp[10 * k + a];
+      closest[3 * n + a] = tmp[10 * k + 3 + a];
+      normal[3 * n + a] = tmp[10 * k + 6 + a];
+    }
+    if (cell)
+      cell[n] = tc[k];
+    if (dist)
+      dist[n] = tmp[10 * k + 9];
+    if (src_index)
+      src_index[n] = k * step;
+    n++;
+  }
+  free(ok);
+  free(tmp);
+  free(tc);
+  return n;
+}
+
 /* ------------------------------------------------------------------ solvers */
 #define REAL double
 #define SUF(x) x##_f64

@@ -47,6 +47,10 @@ def _load():
         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, _f64p, C.c_int64, C.c_double, C.c_double,
         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p]
+    lib.orc_correspond_f64.restype = C.c_int64
+    lib.orc_correspond_f64.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_int64, _f64p, C.c_int64, C.c_double, C.c_int, C.c_int,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_solve.restype = C.c_int
     lib.orc_solve.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p, _f64p]
@@ -140,6 +144,21 @@ class Mesh:
             float(min_dot), int(grid), int(threads or num_threads()), _ptr(out["origin"]),
             _ptr(out["origin_normal"]), _ptr(out["closest"]), _ptr(out["normal"]),
             _ptr(out["cell"]), _ptr(out["dist"]), _ptr(out["src_index"]), _ptr(out["kind"]))
+        return {k: v[:n] for k, v in out.items()}
+
+    def correspond_f64(self, src, T=None, step=1, max_dist=10.0, grid=True, threads=None):
+        """The filter with OutputPrecision = DOUBLE_PRECISION; rows in index order."""
+        src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
+        T = np.eye(4) if T is None else np.ascontiguousarray(T, np.float64).reshape(4, 4)
+        step = max(1, int(step))
+        nk = (len(src) + step - 1) // step
+        out = dict(origin=np.zeros((nk, 3), np.float64), closest=np.zeros((nk, 3), np.float64),
+                   normal=np.zeros((nk, 3), np.float64), cell=np.zeros(nk, np.int32),
+                   dist=np.zeros(nk, np.float64), src_index=np.zeros(nk, np.int64))
+        n = lib().orc_correspond_f64(
+            self.h, _ptr(src), len(src), T.reshape(-1), step, float(max_dist), int(grid),
+            int(threads or num_threads()), _ptr(out["origin"]), _ptr(out["closest"]),
+            _ptr(out["normal"]), _ptr(out["cell"]), _ptr(out["dist"]), _ptr(out["src_index"]))
         return {k: v[:n] for k, v in out.items()}
 
     def icp(self, src, metric=1, max_iter=50, max_landmarks=200, max_dist=10.0,

@@ -374,6 +374,45 @@ def test_filter_surface(icpx, synth, oracle):
     assert np.array_equal(g.GetOutput(0).GetPoints(), ref["origin"])
     assert np.array_equal(g.GetOutput(1).GetPoints(), ref["closest"])
     assert np.array_equal(g.Cells, ref["cell"])
+    # double output precision: the rows as computed, unrounded; no origin normals on that path
+    f.SetOutputPrecision(F.DOUBLE_PRECISION)
+    f.Update()
+    ref = mesh_t.correspond_f64(moved, T=Tinv, step=1, max_dist=0.05, grid=True)
+    out0, out1 = f.GetOutput(0), f.GetOutput(1)
+    assert out0.GetPoints().dtype == np.float64 and out1.GetPointNormals().dtype == np.float64
+    assert len(ref["cell"]) > 0 and np.array_equal(f.Cells, ref["cell"])
+    assert np.array_equal(out0.GetPoints(), ref["origin"])
+    assert np.array_equal(out1.GetPoints(), ref["closest"])
+    assert np.array_equal(f.Distances, ref["dist"])
+    assert np.abs(out1.GetPointNormals() - ref["normal"]).max() <= 1e-14
+    assert out0.GetPointNormals() is None
+
+
+def test_double_rows_on_edges_and_vertices(icpx, synth, oracle, small):
+    """icpx_correspond_f64 where the closest point falls on faces, edges and vertices (the
+    edge and vertex normals are summed from the fp64 face normals on the spot), with
+    caller-supplied cell normals as well."""
+    c, mesh = small
+    q = queries_around(synth, c["target_xyz"], c["target_tri"], 3000, seed=5)
+    ref = mesh.correspond_f64(q, step=1, max_dist=1e30, grid=False)
+    kinds = mesh.correspond(q, step=1, max_dist=1e30, grid=False)["kind"]
+    assert {0, 1, 2} <= set(np.unique(kinds))
+    ctx = icpx.Context(0)
+    ctx.set_target(c["target_xyz"], c["target_tri"])
+    ctx.set_source(q)
+    got = ctx.correspond_f64(np.eye(4), step=1, max_dist=1e30)
+    for k in ("cell", "src_index", "origin", "closest", "dist"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.abs(got["normal"] - ref["normal"]).max() <= 1e-14
+    cn = synth.gaussian(3, 7, 3 * len(c["target_tri"])).reshape(-1, 3).astype(np.float32)
+    cn /= np.linalg.norm(cn, axis=1, keepdims=True)
+    ctx.set_target(c["target_xyz"], c["target_tri"], cn)
+    ref = oracle.Mesh(c["target_xyz"], c["target_tri"], cn).correspond_f64(
+        q, T=synth.rigid(rz=0.2), step=3, max_dist=0.5, grid=False)
+    got = ctx.correspond_f64(synth.rigid(rz=0.2), step=3, max_dist=0.5)
+    assert 0 < len(ref["cell"]) and np.array_equal(got["cell"], ref["cell"])
+    assert np.array_equal(got["closest"], ref["closest"])
+    assert np.abs(got["normal"] - ref["normal"]).max() <= 1e-14
 
 
 def test_golden_fixtures(icpx, synth):

@@ -217,9 +217,6 @@ def test_filter_defaults_and_failures(capsys):
     assert f.RequestData() == 0 and "only support float" in capsys.readouterr().err
     f.SetInputData(0, vtkPolyData(xyz, tri))
     f.SetInputData(1, vtkPolyData(xyz, tri))
-    f.SetOutputPrecision(F.DOUBLE_PRECISION)
-    assert f.RequestData() == 0 and "Double output" in capsys.readouterr().err
-    f.SetOutputPrecision(F.SINGLE_PRECISION)
     f.SetInputData(1, vtkPolyData(xyz))                        # a target without polygons
     assert f.RequestData() == 0 and "No polygons" in capsys.readouterr().err
     f.SetInputData(1, vtkPolyData(xyz, tri))
