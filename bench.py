@@ -42,6 +42,8 @@ def make_workload(name, rank, synth):
         c = synth.config_c3()
     elif name == "c4":
         c = synth.config_c4()
+    elif name == "c5big":  # partial overlap and 20 % outliers at C3's size (development)
+        c = synth.config_c5(nu=1000, nv=500, npts=1_200_000)
     elif name == "c3small":  # for quick functional runs only
         c = synth.config_c3(nu=200, nv=100, npts=50_000)
     else:

@@ -209,6 +209,7 @@ struct icpx_ctx
   int use_cert = 1;      // the shortcut keeps certificates (icpx_set_local(2) turns them off)
   int holdoff_len = 8;   // length of the next suspension: doubles each time one is called for
   bool after_cold = false; // the last pass was a cold one
+  double cap2 = DBL_MAX;   // this pass's distance threshold, squared (what the searches stop at)
   bool probation = false; // back from a suspension: one more bad pass suspends it again
   bool last_local = false;   // the pass enqueued last tried the shortcut
   bool stat_local = false;   // ... and so did the pass whose figures are pending in h_stat
@@ -1411,6 +1412,7 @@ static int run_search3(icpx_ctx* c)
   a.ovf_list = c->d_ovf_list;
   a.ovf_best = c->d_ovf_best;
   a.qlist = nullptr;
+  a.cap2 = c->cap2;
   a.refill = c->refill_override > 0 ? c->refill_override : (c->hint_valid ? 40 : REFILL3);
   hipStream_t st = c->stream;
   const unsigned grid = nblk(c->nq, 256);
@@ -1481,6 +1483,7 @@ static int run_search3(icpx_ctx* c)
     wide.hint = c->d_hint;
     wide.use_hint = 1;
     wide.scene_max = c->scene_max;
+    wide.cap2 = c->cap2;
     widep = &wide;
   }
   if (L == 1)
@@ -1499,6 +1502,13 @@ template <int G>
 static void launch_search2(const Search2Args& a, unsigned grid, hipStream_t st)
 {
   k_search2<G><<<grid, 256, 0, st>>>(a);
+}
+
+// The distance beyond which a pass's searches need not look: the filter's threshold, a hair
+// wider (a correspondence at the threshold itself is dropped anyway).
+static void set_cap(icpx_ctx* c, double max_dist)
+{
+  c->cap2 = (max_dist > 0.0 && max_dist < 1e100) ? max_dist * max_dist * (1.0 + 1e-12) : DBL_MAX;
 }
 
 static int run_search(icpx_ctx* c)
@@ -1531,6 +1541,7 @@ static int run_search(icpx_ctx* c)
     a.hint = c->d_hint;
     a.use_hint = c->hint_valid ? 1 : 0;
     a.scene_max = c->scene_max;
+    a.cap2 = c->cap2;
     ScopedTimer tm(c, 0);
     switch (G)
     {
@@ -1646,6 +1657,7 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * ICPX_NSUMS, st));
     return ICPX_OK;
   }
+  set_cap(c, max_dist);
   rc = run_search(c);
   if (rc)
     return rc;
@@ -1762,6 +1774,7 @@ extern "C" int icpx_correspond(icpx_ctx* c, const double T[16], int64_t step, do
     c->rows_cap = nq;
   }
   c->run_active = false;
+  set_cap(c, max_dist);
   rc = set_transform(c, T, 0);
   if (!rc)
     rc = run_search(c);
@@ -1882,6 +1895,7 @@ extern "C" int icpx_correspond_f64(icpx_ctx* c, const double T[16], int64_t step
     c->rows64_cap = nq;
   }
   c->run_active = false;
+  set_cap(c, max_dist);
   rc = set_transform(c, T, 0);
   if (!rc)
     rc = run_search(c);

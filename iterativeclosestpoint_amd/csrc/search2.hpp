@@ -304,6 +304,7 @@ struct Search2Args
   int32_t* hint;
   int use_hint;
   float scene_max; // largest |coordinate| of the target's bounds
+  double cap2;     // square of the distance beyond which nothing needs to be found (DBL_MAX: none)
 };
 
 template <int G>
@@ -396,6 +397,8 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
     const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
     eabs = smax * 2.3841858e-07f * 1.0000002f; // 2^-22 of the largest coordinate, rounded up
     tau = 1e-9 * (double)smax;
+    if (a.cap2 < 1e300)
+      set_best(a.cap2);
     if (a.use_hint)
     {
       const int32_t hs = a.hint[q];
@@ -403,11 +406,15 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
       {
         d3 P0, P1, P2;
         load_tri(a.tverts, hs, P0, P1, P2);
-        set_best(tri_d2_screen(x, P0, P1, P2));
-        if (j == 0)
-          ring[g][0] = hs;
-        cnt = 1;
-        hs_used = hs;
+        const double ds = tri_d2_screen(x, P0, P1, P2);
+        if (ds < best)
+        {
+          set_best(ds);
+          if (j == 0)
+            ring[g][0] = hs;
+          cnt = 1;
+          hs_used = hs;
+        }
       }
     }
     if (j == 0)

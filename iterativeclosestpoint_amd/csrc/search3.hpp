@@ -181,6 +181,11 @@ struct Search3Args
   double* ovf_best;     // their screened minimum, indexed by query
   const uint32_t* qlist; // persistent kernel: serve only these queries (count in counters[3]), or null
   int refill;            // pooled kernels: idle lanes of a wavefront that trigger taking new queries
+  // The filter drops a correspondence whose distance is not below MaximumDistance
+  // (ICP/vtkPolyDataCorrespondenceFilter.cxx:122), so nothing farther than that needs to
+  // be found: its square is every query's first bound (DBL_MAX: none).  A query with
+  // nothing within it ends without a winner (hint -1), which the finalize kernels drop.
+  double cap2;
 };
 
 constexpr int RING3 = 8;
@@ -269,6 +274,8 @@ __device__ __forceinline__ void search3_body(const Search3Args& a, unsigned bloc
       set_best(a.ovf_best[q]); // the final screened minimum is already known
     else
     {
+      if (a.cap2 < 1e300)
+        set_best(a.cap2);
       int32_t hs = a.use_hint ? a.hint[q] : -1;
       if (hs < 0 && a.tcodes)
       {
@@ -290,10 +297,14 @@ __device__ __forceinline__ void search3_body(const Search3Args& a, unsigned bloc
       {
         d3 P0, P1, P2;
         load_tri(a.tverts, hs, P0, P1, P2);
-        set_best(tri_d2_screen(x, P0, P1, P2));
-        ring[0][tid] = hs;
-        cnt = 1;
-        hs_used = hs;
+        const double ds = tri_d2_screen(x, P0, P1, P2);
+        if (ds < best)
+        {
+          set_best(ds);
+          ring[0][tid] = hs;
+          cnt = 1;
+          hs_used = hs;
+        }
       }
     }
   }
@@ -590,6 +601,8 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
           const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
           eabs = smax * 2.3841858e-07f * 1.0000002f;
           tau = 1e-9 * (double)smax;
+          if (a.cap2 < 1e300)
+            set_best(a.cap2);
           int32_t hs = a.use_hint ? a.hint[q] : -1;
           if (hs < 0 && a.tcodes)
           {
@@ -610,10 +623,14 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
           {
             d3 P0, P1, P2;
             load_tri(a.tverts, hs, P0, P1, P2);
-            set_best(tri_d2_screen(x, P0, P1, P2));
-            ring[0][tid] = hs;
-            cnt = 1;
-            hs_used = hs;
+            const double ds = tri_d2_screen(x, P0, P1, P2);
+            if (ds < best)
+            {
+              set_best(ds);
+              ring[0][tid] = hs;
+              cnt = 1;
+              hs_used = hs;
+            }
           }
         }
         dry = __ballot(want && nq_ >= total) != 0ull;
@@ -955,6 +972,8 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
           eabs = smax * 2.3841858e-07f * 1.0000002f;
           tau = 1e-9 * (double)smax;
           tauf = 1.0000001e-9f * smax;
+          if (a.cap2 < 1e300)
+            set_best(a.cap2);
           int32_t hs = a.use_hint ? a.hint[q] : -1;
           if (hs < 0 && a.tcodes)
           {
@@ -975,10 +994,14 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
           {
             d3 P0, P1, P2;
             load_tri(a.tverts, hs, P0, P1, P2);
-            set_best(tri_d2_screen(x, P0, P1, P2));
-            ring[0][tid] = hs;
-            cnt = 1;
-            hs_used = hs;
+            const double ds = tri_d2_screen(x, P0, P1, P2);
+            if (ds < best)
+            {
+              set_best(ds);
+              ring[0][tid] = hs;
+              cnt = 1;
+              hs_used = hs;
+            }
           }
         }
         dry = __ballot(want && nq_ >= total) != 0ull;
@@ -1222,6 +1245,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
       eabs = smax * 2.3841858e-07f * 1.0000002f;
       tau = 1e-9 * (double)smax;
       tauf = 1.0000001e-9f * smax;
+      if (a.cap2 < 1e300)
+        set_best(a.cap2);
       int32_t hs = a.use_hint ? a.hint[q] : -1;
       // last pass's winner is a poor start when the pose has moved by many triangle widths
       // since (its centroid is then several of its radii away): such a query is seeded
@@ -1267,10 +1292,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
       {
         d3 P0, P1, P2;
         load_tri(a.tverts, hs, P0, P1, P2);
-        set_best(tri_d2_screen(x, P0, P1, P2));
-        ring[0][lane] = hs;
-        cnt = 1;
-        hs_used = hs;
+        const double ds = tri_d2_screen(x, P0, P1, P2);
+        if (ds < best)
+        {
+          set_best(ds);
+          ring[0][lane] = hs;
+          cnt = 1;
+          hs_used = hs;
+        }
       }
     }
 

@@ -20,7 +20,8 @@ def main():
     ap.add_argument("--local", type=int, default=1)
     ap.add_argument("--persistent", type=int, default=-1)
     a = ap.parse_args()
-    c = {"c3": synth.config_c3, "c4": synth.config_c4}[a.workload]()
+    c = {"c3": synth.config_c3, "c4": synth.config_c4,
+         "c5big": lambda: synth.config_c5(nu=1000, nv=500, npts=1_200_000)}[a.workload]()
     metric = c["metric"]
     ctx = icpx.Context(0)
     if a.width:

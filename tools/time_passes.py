@@ -32,7 +32,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--refill", type=int, default=0)
     a = ap.parse_args()
-    c = {"c3": synth.config_c3, "c4": synth.config_c4}[a.workload]()
+    c = {"c3": synth.config_c3, "c4": synth.config_c4,
+         "c5big": lambda: synth.config_c5(nu=1000, nv=500, npts=1_200_000)}[a.workload]()
     metric = c["metric"]
     Tinv = np.linalg.inv(c["truth"])
     for w in [int(x) for x in a.widths.split(",")]:
