@@ -97,14 +97,17 @@ __global__ void k_set_state(RunState* s, Mat16 T, int reset)
 
 // What a pass without the fused sums did to the shortcut's certificates (the fused pass
 // says it in k_reduce_partials).
-__global__ void k_cert_mark(RunState* s, int mode)
+__global__ void k_cert_mark(RunState* s, int mode, double cap2)
 {
   if (s->done)
     return;
   if (mode && threadIdx.x < 12)
     s->cert_T[threadIdx.x] = s->T[threadIdx.x];
   if (threadIdx.x == 0)
+  {
     s->cert_ok = mode ? 1 : 0;
+    s->cert_cap2 = cap2;
+  }
 }
 
 __global__ void k_solve(RunState* s, const double* __restrict__ sums, int metric, double ox,
@@ -128,12 +131,12 @@ __global__ void k_solve(RunState* s, const double* __restrict__ sums, int metric
 __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ partials,
   int nblocks, double* sums, uint32_t* __restrict__ counters, RunState* s, int cert_mode,
   int metric, double ox, double oy, double oz, int check_mean, double max_mean, RunRecord* rec,
-  uint32_t seq, uint32_t* ticket)
+  uint32_t seq, uint32_t* ticket, double cap2)
 {
   __shared__ double tot[ICPX_NSUMS];
   __shared__ uint32_t last;
   const bool ran = reduce_partials_body(partials, nblocks, sums, &s->done, counters, nullptr, s->T,
-    s->cert_T, &s->cert_ok, cert_mode);
+    s->cert_T, &s->cert_ok, cert_mode, cap2, &s->cert_cap2);
   if (threadIdx.x == 0)
   {
     __threadfence();
@@ -209,6 +212,8 @@ struct icpx_ctx
   int use_cert = 1;      // the shortcut keeps certificates (icpx_set_local(2) turns them off)
   int holdoff_len = 8;   // length of the next suspension: doubles each time one is called for
   bool after_cold = false; // the last pass was a cold one
+  int since_cold = 0;      // passes since the last cold one
+  bool pass_certs = false; // the pass being enqueued keeps every query's certificate up to date
   double cap2 = DBL_MAX;   // this pass's distance threshold, squared (what the searches stop at)
   bool probation = false; // back from a suspension: one more bad pass suspends it again
   bool last_local = false;   // the pass enqueued last tried the shortcut
@@ -1221,8 +1226,10 @@ static void launch_search3(const Search3Args& a, unsigned grid, unsigned pgrid, 
 {
   if (wide && pgrid && mode == 1)
     k_fallback<L><<<pgrid, 256, 0, st>>>(a, *wide);
+  else if (mode == 3 && a.cert)
+    k_search3w<L, true><<<wgrid, 64, 0, st>>>(a);
   else if (mode == 3)
-    k_search3w<L><<<wgrid, 64, 0, st>>>(a);
+    k_search3w<L, false><<<wgrid, 64, 0, st>>>(a);
   else if (pgrid && mode == 2)
     k_search3q<L><<<pgrid, 256, 0, st>>>(a);
   else if (pgrid)
@@ -1413,6 +1420,11 @@ static int run_search3(icpx_ctx* c)
   a.ovf_best = c->d_ovf_best;
   a.qlist = nullptr;
   a.cap2 = c->cap2;
+  a.cert = nullptr; // (set below, once the pass's kernels are known)
+  a.cert_T = c->d_state->cert_T;
+  a.cert_ok = &c->d_state->cert_ok;
+  a.cert_cap2 = &c->d_state->cert_cap2;
+  a.widen_max = 0.25f * c->mesh_edge;
   a.refill = c->refill_override > 0 ? c->refill_override : (c->hint_valid ? 40 : REFILL3);
   hipStream_t st = c->stream;
   const unsigned grid = nblk(c->nq, 256);
@@ -1421,6 +1433,19 @@ static int run_search3(icpx_ctx* c)
   if (rc)
     return rc;
   c->last_local = use_local;
+  // by regime: a whole pass over a cloud about as dense as the mesh goes one walk per
+  // wavefront (neighbouring queries share their walk); what the shortcut left over, or a
+  // sparse cloud, is scattered and goes one pooled lane per query
+  int mode = c->persistent;
+  if (mode == 4)
+    mode = (!use_local && c->nq * 4 >= c->nt) ? 3 : 1;
+  // the wavefront walk, the pooled lanes and the shortcut keep certificates; the other
+  // variants do not, and a pass of theirs leaves the certificates behind
+  // (nor does the wavefront walk on a cold pass and the one after it: those moves outrun
+  // any certificate)
+  c->since_cold = c->hint_valid ? c->since_cold + 1 : 0;
+  c->pass_certs = c->use_cert && (mode == 1 || (mode == 3 && c->since_cold >= 2));
+  a.cert = c->pass_certs ? c->d_cert : nullptr;
   ScopedTimer tm(c, 0);
   if (!c->counters_clean)
     HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), st));
@@ -1438,9 +1463,9 @@ static int run_search3(icpx_ctx* c)
     la.grid = c->qgrid;
     la.eps = c->nbr_eps;
     la.fallback = c->d_fallback;
-    la.cert = c->use_cert ? c->d_cert : nullptr;
     la.cert_T = c->d_state->cert_T;
     la.cert_ok = &c->d_state->cert_ok;
+    la.cert_cap2 = &c->d_state->cert_cap2;
     k_search_local<<<grid, 256, 0, st>>>(la);
     a.qlist = c->d_fallback; // the tree kernel serves what is left,
     a.use_hint = 1;          // starting from the triangles the shortcut reached
@@ -1460,12 +1485,6 @@ static int run_search3(icpx_ctx* c)
   unsigned wgrid = nblk(c->nq, 64);
   if (wgrid > (unsigned)c->num_cus * (unsigned)c->wave_blocks)
     wgrid = (unsigned)c->num_cus * (unsigned)c->wave_blocks;
-  // by regime: a whole pass over a cloud about as dense as the mesh goes one walk per
-  // wavefront (neighbouring queries share their walk); what the shortcut left over, or a
-  // sparse cloud, is scattered and goes one pooled lane per query
-  int mode = c->persistent;
-  if (mode == 4)
-    mode = (!use_local && c->nq * 4 >= c->nt) ? 3 : 1;
   // the shortcut's leftovers: a short list goes one wavefront per query over the 64-ary tree
   Search2Args wide;
   const Search2Args* widep = nullptr;
@@ -1484,6 +1503,7 @@ static int run_search3(icpx_ctx* c)
     wide.use_hint = 1;
     wide.scene_max = c->scene_max;
     wide.cap2 = c->cap2;
+    wide.cert = a.cert;
     widep = &wide;
   }
   if (L == 1)
@@ -1514,6 +1534,7 @@ static void set_cap(icpx_ctx* c, double max_dist)
 static int run_search(icpx_ctx* c)
 {
   c->last_local = false;
+  c->pass_certs = false;
   const int G = pick_width(c);
   if (G == 1)
     return run_search3(c);
@@ -1542,6 +1563,7 @@ static int run_search(icpx_ctx* c)
     a.use_hint = c->hint_valid ? 1 : 0;
     a.scene_max = c->scene_max;
     a.cap2 = c->cap2;
+    a.cert = nullptr;
     ScopedTimer tm(c, 0);
     switch (G)
     {
@@ -1679,7 +1701,7 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     else
       k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
   }
-  const int cert_mode = (c->last_local && c->use_cert) ? 1 : 0;
+  const int cert_mode = c->pass_certs ? 1 : 0;
   if (fuse_solve)
   {
     // (a run's pass on one rank: the solve rides on the reduction's launch)
@@ -1687,7 +1709,7 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     const int slot = (int)(c->run_it & 3);
     k_reduce_solve<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, c->d_counters, c->d_state,
       cert_mode, p.metric, c->origin[0], c->origin[1], c->origin[2], p.check_mean_distance,
-      p.max_mean_distance, c->d_rec + slot, ++c->rec_seq, c->d_ticket);
+      p.max_mean_distance, c->d_rec + slot, ++c->rec_seq, c->d_ticket, c->cap2);
     c->slot_seq[slot] = c->rec_seq;
     c->pass_local[slot] = c->last_local;
     c->run_it++;
@@ -1695,7 +1717,7 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
   else
     k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, &c->d_state->done,
       c->d_counters, want_stat ? c->d_stat : nullptr, c->d_state->T, c->d_state->cert_T,
-      &c->d_state->cert_ok, cert_mode);
+      &c->d_state->cert_ok, cert_mode, c->cap2, &c->d_state->cert_cap2);
   LAUNCHCHK();
   if (c->d_counters)
     c->counters_clean = true;
@@ -1780,7 +1802,7 @@ extern "C" int icpx_correspond(icpx_ctx* c, const double T[16], int64_t step, do
     rc = run_search(c);
   if (rc)
     return rc;
-  k_cert_mark<<<1, 64, 0, c->stream>>>(c->d_state, (c->last_local && c->use_cert) ? 1 : 0);
+  k_cert_mark<<<1, 64, 0, c->stream>>>(c->d_state, c->pass_certs ? 1 : 0, c->cap2);
   FinalArgs f;
   fill_final(c, f, max_dist, min_dot, use_sn, use_sn != 0);
   f.o_origin = c->r_origin;
@@ -1901,7 +1923,7 @@ extern "C" int icpx_correspond_f64(icpx_ctx* c, const double T[16], int64_t step
     rc = run_search(c);
   if (rc)
     return rc;
-  k_cert_mark<<<1, 64, 0, st>>>(c->d_state, (c->last_local && c->use_cert) ? 1 : 0);
+  k_cert_mark<<<1, 64, 0, st>>>(c->d_state, c->pass_certs ? 1 : 0, c->cap2);
   Rows64Args a;
   a.qpos = c->d_qpos;
   a.qk = c->d_qk;

@@ -220,9 +220,10 @@ struct LocalArgs
   uint32_t* fallback;   // queries left to the tree kernel; their count is counters[3]
   // certificates: per query, how far it may still move before last pass's winner has to be
   // looked at again (0: no certificate); the transform they refer to; whether they count
-  float* cert;
+  // (the certificates themselves are s.cert, shared with the tree kernels)
   const double* cert_T;
   const int32_t* cert_ok;
+  const double* cert_cap2; // the cap the far certificates were made for
 };
 
 constexpr int LOCAL_STEPS = 16; // moves along the surface before a query is given up
@@ -257,15 +258,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   const bool active = q < a.nq;
   const int64_t qc = active ? q : 0;
   const float p3[3] = { a.qpos[3 * qc], a.qpos[3 * qc + 1], a.qpos[3 * qc + 2] };
-  const float slack0 = la.cert ? la.cert[qc] : 0.f;
+  const float slack0 = a.cert ? a.cert[qc] : 0.f;
   const int32_t stopv = a.T.stop ? *a.T.stop : 0;
   int32_t okv = 0;
 #pragma unroll
   for (int i = 0; i < 12; i++)
     T.m[i] = a.T.T[i];
-  if (la.cert)
+  double capv = 0.0;
+  if (a.cert)
   {
     okv = *la.cert_ok;
+    capv = *la.cert_cap2;
 #pragma unroll
     for (int i = 0; i < 12; i++)
       Tc.m[i] = la.cert_T[i];
@@ -296,7 +299,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   int32_t hs = -1;
   bool local = false, certified = false;
   float sec2 = 0.f; // lower bound of the squared distance of every triangle but the best
-  const bool cert_on = la.cert && a.use_hint && __builtin_amdgcn_readfirstlane(okv) != 0;
+  const bool cert_on = a.cert && a.use_hint && __builtin_amdgcn_readfirstlane(okv) != 0;
+  // far certificates hold for the cap they were made for, or a smaller one
+  const bool far_on = cert_on && a.cap2 <= uniform_f64(capv) * (1.0 + 1e-12);
 
   auto set_best = [&](double nb) {
     const double r = sqrt(nb) + tau;
@@ -320,41 +325,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
     eabs = smax * 2.3841858e-07f * 1.0000002f;
     tau = 1e-9 * (double)smax;
-    if (cert_on)
+    if (cert_on && (slack > 0.f || (slack < 0.f && far_on)))
     {
-      if (slack > 0.f)
+      // the move since the certificate was last brought up to date
+      const d3 xp = xform(Tc, p3);
+      const double mx = x.x - xp.x, my = x.y - xp.y, mz = x.z - xp.z;
+      const float m2 = __double2float_ru(mx * mx + my * my + mz * mz);
+      const float mv = __builtin_amdgcn_sqrtf(m2) * 1.000001f;
+      // a winner stands while the others stay farther (each side moves by mv); "nothing
+      // within the cap" stands while the nearest stays beyond it (one side moves)
+      const float left = slack > 0.f ? slack - 2.000001f * mv - 1e-30f
+                                     : -slack - 1.000001f * mv - 1e-30f;
+      if (left > 0.f)
       {
-        // the move since the certificate was last brought up to date
-        const d3 xp = xform(Tc, p3);
-        const double mx = x.x - xp.x, my = x.y - xp.y, mz = x.z - xp.z;
-        const float m2 = __double2float_ru(mx * mx + my * my + mz * mz);
-        const float mv = __builtin_amdgcn_sqrtf(m2) * 1.000001f;
-        const float left = slack - 2.000001f * mv - 1e-30f;
-        if (left > 0.f)
-        {
-          certified = true;
-          la.cert[q] = left * 0.9999999f;
-        }
+        certified = true;
+        a.cert[q] = (slack > 0.f ? left : -left) * 0.9999999f;
       }
     }
     hs = (a.use_hint && !certified) ? a.hint[q] : -1;
   }
   if (active)
   {
-    if (hs < 0 && a.tcodes && !certified)
-    {
-      const uint64_t code = morton63(xf, yf, zf, a.box.lo, a.box.inv);
-      int64_t lo = 0, hi = a.nt; // first position with tcodes[pos] >= code
-      while (lo < hi)
-      {
-        const int64_t mid = (lo + hi) >> 1;
-        if (a.tcodes[mid] < code)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
-      hs = (int32_t)min(lo, a.nt - 1);
-    }
+    // (a query without a winner had nothing within the cap last time: the tree kernel looks
+    // again, from the root)
     // a triangle can settle the query only if the query is within eps/2 of it; its box
     // gives a cheap lower bound of that distance
     gx = (xf - la.grid.base[0]) * la.grid.inv_step;
@@ -391,6 +384,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         }
       }
       if (step == LOCAL_STEPS)
+        break;
+      // a query a few list radii from its start triangle, yet beyond reach, is off the
+      // surface rather than displaced along it: no walk along the surface brings it within
+      // reach, so it goes to the tree kernel at once
+      if (qbox_g2(wb, gx, gy, gz) <= 64.f * reach_g)
         break;
       // move to the listed triangle whose box centre is nearest to the query
       float bestc = INFINITY;
@@ -520,20 +518,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 
   // the certificate of a query settled with a single contender; none for any other query
   // that was looked at
-  if (la.cert && active && !certified)
+  if (a.cert && active && !certified && local)
   {
     float slack = 0.f;
     if (local && cnt == 1)
-      slack = __builtin_amdgcn_sqrtf(sec2) * 0.999999f - __double2float_ru(sqrt(best)) * 1.000001f -
-        2.1f * (float)tau - eabs;
-    la.cert[q] = fmaxf(slack, 0.f);
+    {
+      const float dw = __double2float_ru(sqrt(best));
+      slack = __builtin_amdgcn_sqrtf(sec2) * 0.999999f - dw * 1.000001f - 2.1f * (float)tau -
+        fminf(eabs, 0.2f * eabs * eabs / fmaxf(dw, 1e-30f)); // (see make_certificate)
+    }
+    a.cert[q] = fmaxf(slack, 0.f);
   }
 
 #ifdef ICPX_STATS
   {
     // development build only: queries let through on their certificate / given a new one
     const unsigned long long mc = __ballot(certified);
-    const unsigned long long mn = __ballot(la.cert && active && !certified && la.cert[q] > 0.f);
+    const unsigned long long mn = __ballot(a.cert && active && !certified && a.cert[q] != 0.f);
     if (lane == 0)
     {
       atomicAdd(&g_stats[6], (unsigned long long)__popcll(mc));

@@ -493,7 +493,7 @@ __device__ __forceinline__ bool reduce_partials_body(
   const double* __restrict__ partials, int nblocks, double* __restrict__ sums,
   const int32_t* __restrict__ stop, uint32_t* __restrict__ counters, double* __restrict__ stat,
   const double* __restrict__ T, double* __restrict__ cert_T, int32_t* __restrict__ cert_ok,
-  int cert_mode)
+  int cert_mode, double cap2 = 0.0, double* __restrict__ cert_cap2 = nullptr)
 {
   if (stop && *stop)
     return false; // the pass did not run
@@ -503,7 +503,11 @@ __device__ __forceinline__ bool reduce_partials_body(
     if (cert_mode && l < 12)
       cert_T[l] = T[l];
     if (l == 0)
+    {
       *cert_ok = cert_mode ? 1 : 0;
+      if (cert_cap2)
+        *cert_cap2 = cap2;
+    }
   }
   if (counters && i == 0 && l < 4)
   {
@@ -540,10 +544,10 @@ __global__ __launch_bounds__(64) void k_reduce_partials(
   const double* __restrict__ partials, int nblocks, double* __restrict__ sums,
   const int32_t* __restrict__ stop, uint32_t* __restrict__ counters, double* __restrict__ stat,
   const double* __restrict__ T, double* __restrict__ cert_T, int32_t* __restrict__ cert_ok,
-  int cert_mode)
+  int cert_mode, double cap2, double* __restrict__ cert_cap2)
 {
   (void)reduce_partials_body(partials, nblocks, sums, stop, counters, stat, T, cert_T, cert_ok,
-    cert_mode);
+    cert_mode, cap2, cert_cap2);
 }
 
 // Query set-up: gather the kept points (and normals) of the shard into Morton order.

@@ -305,6 +305,7 @@ struct Search2Args
   int use_hint;
   float scene_max; // largest |coordinate| of the target's bounds
   double cap2;     // square of the distance beyond which nothing needs to be found (DBL_MAX: none)
+  float* cert;     // certificates (see local.hpp): a query settled here gets none (0); or null
 };
 
 template <int G>
@@ -509,7 +510,11 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
       win = es;
     }
     if (j == 0)
+    {
       a.hint[q] = win;
+      if (a.cert)
+        a.cert[q] = 0.f;
+    }
   }
 }
 

@@ -186,7 +186,68 @@ struct Search3Args
   // be found: its square is every query's first bound (DBL_MAX: none).  A query with
   // nothing within it ends without a winner (hint -1), which the finalize kernels drop.
   double cap2;
+  // Certificates (see local.hpp): per query, > 0: its winner stands while twice the query's
+  // move stays below this; < 0: nothing comes within the cap while the move stays below
+  // the magnitude; 0: none.  Written for every query a kernel settles (null: not kept).
+  float* cert;
+  const double* cert_T;    // the transform the certificates were last brought up to date for,
+  const int32_t* cert_ok;  // whether they are up to date at all,
+  const double* cert_cap2; // and the cap the far ones were made for (k_search3w checks them
+                           // itself; elsewhere k_search_local does before the tree kernel runs)
+  // A box turned away just beyond the bound says little about the triangles in it, so a
+  // search that is to leave a useful certificate looks a little farther than it must: by
+  // eight times the query's move since the last pass, at least two rounding allowances, at
+  // most widen_max (a fraction of the mesh's edge length).  Triangles in that margin are
+  // screened and counted among "the others" with their true distance.
+  float widen_max;
 };
+
+// the margin a query's search is widened by (see Search3Args::widen_max)
+__device__ __forceinline__ float widen_of(const Search3Args& a, const Xf& T, const float* p,
+  const d3& x, float eabs)
+{
+  if (!a.cert)
+    return 0.f;
+  float mv = 0.f;
+  // (a cold pass has no previous pose to measure the move from)
+  if (a.use_hint && __builtin_amdgcn_readfirstlane(*a.cert_ok) != 0)
+  {
+    Xf Tc;
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+      Tc.m[i] = uniform_f64(a.cert_T[i]);
+    const d3 xp = xform(Tc, p);
+    const double mx = x.x - xp.x, my = x.y - xp.y, mz = x.z - xp.z;
+    mv = __builtin_amdgcn_sqrtf(__double2float_ru(mx * mx + my * my + mz * mz));
+  }
+  return fminf(fmaxf(8.f * mv, 2.f * eabs), fmaxf(a.widen_max, 2.f * eabs));
+}
+
+// The certificate of a finished query.  cnt: contenders; best: the winner's screened squared
+// distance; sec2: lower bound of the squared distance of every other triangle that was
+// screened; minraw: smallest raw squared box distance (box_d2) among the boxes turned away;
+// minlin: smallest lower bound, as a distance, of triangles turned away by cheap bounds.
+__device__ __forceinline__ float make_certificate(int cnt, double best, float sec2, float minraw,
+  float minlin, double tau, float eabs, double cap2)
+{
+  // (a raw box distance exceeds the true one by at most sqrt(3) eabs)
+  const float dbox = __builtin_amdgcn_sqrtf(minraw) * 0.999999f - 1.7320509f * eabs;
+  const float others = fminf(fminf(dbox, minlin), __builtin_amdgcn_sqrtf(sec2) * 0.999999f);
+  // what the screened distance of the winner may be off by: a few units in the last place
+  // of the squared coordinates, i.e. ~0.02 eabs^2 / distance, never more than eabs
+  const float dw = __double2float_ru(sqrt(cnt == 1 ? best : cap2));
+  const float slop = fminf(eabs, 0.2f * eabs * eabs / fmaxf(dw, 1e-30f)) + 2.1f * (float)tau;
+  float c = 0.f;
+  if (cnt == 1)
+    c = others - dw * 1.000001f - slop;
+  else if (cnt == 0 && cap2 < 1e300)
+    c = -(others - dw * 1.000001f - slop);
+  // (a near certificate must be positive, a far one negative; infinities mean nothing was
+  // ever turned away, which only a mesh without triangles does)
+  if (cnt == 1)
+    return (c > 0.f && c < 1e30f) ? c : 0.f;
+  return (c < 0.f && c > -1e30f) ? c : 0.f;
+}
 
 constexpr int RING3 = 8;
 
@@ -504,6 +565,8 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
   int32_t hs_used = -1;
   uint32_t n = 1, trail = 0;
   float lbleaf = 0.f;
+  float sec2 = INFINITY, minraw = INFINITY; // for the certificate (make_certificate)
+  float widen = 0.f;                        // margin by which the walk looks farther (widen_of)
   bool have = false, fin = false, need_bt = false, atleaf = false;
   bool dry = false; // the pool has run out (same for every lane of the wavefront)
   const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
@@ -520,7 +583,9 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
       cnt = 0; // every older contender was above the old minimum
     best = nb;
     bound = nbound;
-    boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
+    // boxes and triangles are turned away beyond the widened bound
+    const double rw = r + (double)widen;
+    boundf = fminf(fmaxf(__double2float_ru(rw * rw), FLT_MIN), FLT_MAX);
     bboxf = box_bound(boundf, eabs);
   };
 
@@ -536,6 +601,8 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
       const bool ovf = f && cnt > RING3;
       if (f && !tie && !ovf)
         a.hint[q] = (cnt == 1) ? ring[0][tid] : -1;
+      if (f && a.cert)
+        a.cert[q] = make_certificate(cnt, best, sec2, minraw, INFINITY, tau, eabs, a.cap2);
       const unsigned long long mt = __ballot(tie);
       if (mt)
       {
@@ -590,6 +657,8 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
           trail = 0;
           cnt = 0;
           hs_used = -1;
+          sec2 = INFINITY;
+          minraw = INFINITY;
           best = DBL_MAX;
           bound = DBL_MAX;
           boundf = FLT_MAX;
@@ -601,6 +670,7 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
           const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
           eabs = smax * 2.3841858e-07f * 1.0000002f;
           tau = 1e-9 * (double)smax;
+          widen = widen_of(a, T, a.qpos + 3 * q, x, eabs);
           if (a.cap2 < 1e300)
             set_best(a.cap2);
           int32_t hs = a.use_hint ? a.hint[q] : -1;
@@ -658,7 +728,10 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
           if (k == d - 1)
           {
             if (lbleaf > bboxf)
+            {
+              minraw = fminf(minraw, lbleaf);
               need_bt = true;
+            }
             else
               atleaf = true;
           }
@@ -672,6 +745,7 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
         const float lb0 = box_d2(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf);
         const float lb1 = box_d2(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf);
         const bool ok0 = lb0 <= bboxf, ok1 = lb1 <= bboxf;
+        minraw = fminf(minraw, fminf(ok0 ? INFINITY : lb0, ok1 ? INFINITY : lb1));
         if (ok0 || ok1)
         {
           const uint32_t near = (ok1 && (!ok0 || lb1 < lb0)) ? 1u : 0u;
@@ -711,6 +785,10 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
           d3 P0, P1, P2;
           load_tri(a.tverts, s, P0, P1, P2);
           const double d2 = tri_d2_screen(x, P0, P1, P2);
+          // whichever of this triangle and the best so far loses is one of "the others"
+          // (the start triangle, met again, is the best or has lost already)
+          if ((int32_t)s != hs_used)
+            sec2 = fminf(sec2, __double2float_rd(fmax(d2, best)) * 0.999999f);
           if (d2 < best)
             set_best(d2);
           if (d2 <= bound && (int32_t)s != hs_used)
@@ -1146,9 +1224,12 @@ __device__ __forceinline__ uint32_t uni32(uint32_t v)
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-template <int L>
+// CERT: check and keep certificates (a pass right after a cold start does neither: its
+// moves outrun any certificate, and the bookkeeping costs registers).
+template <int L, bool CERT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_search3w(Search3Args a)
 {
+  float* const cert = CERT ? a.cert : nullptr;
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
@@ -1163,6 +1244,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
   if ((int64_t)blockIdx.x * 64 >= total)
     return; // a short list is served by the first blocks; the rest must not queue at the pool
   // (read-only for the whole launch and addressed uniformly: eligible for the scalar path)
+  // certificates are checked here only on a whole pass (a list holds what failed the check)
+  bool cert_on = false, far_on = false;
+  if (cert && a.use_hint && !a.qlist && __builtin_amdgcn_readfirstlane(*a.cert_ok) != 0)
+  {
+    cert_on = true;
+    far_on = a.cap2 <= uniform_f64(*a.cert_cap2) * (1.0 + 1e-12);
+  }
   cfloat4* nodes4 = (cfloat4*)(uintptr_t)a.nodes;
   cfloat4* tpre4 = (cfloat4*)(uintptr_t)a.tpre;
 #ifdef ICPX_STATS
@@ -1178,8 +1266,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     if ((int64_t)base >= total)
       break;
     const int64_t idx = (int64_t)base + lane;
-    const bool active = idx < total;
+    bool active = idx < total;
     const int64_t q = active ? (a.qlist ? (int64_t)a.qlist[idx] : idx) : 0;
+    const float slack = (cert_on && active) ? cert[q] : 0.f;
+    if (__ballot(slack != 0.f) != 0ull)
+    {
+      // as in k_search_local: a query whose certificate covers its move keeps its result
+      // (the certificates' transform is read here, not held across the walk)
+      Xf Tc;
+#pragma unroll
+      for (int i = 0; i < 12; i++)
+        Tc.m[i] = uniform_f64(a.cert_T[i]);
+      if (slack > 0.f || (slack < 0.f && far_on))
+      {
+        const d3 xn = xform(T, a.qpos + 3 * q), xp = xform(Tc, a.qpos + 3 * q);
+        const double mx = xn.x - xp.x, my = xn.y - xp.y, mz = xn.z - xp.z;
+        const float mv =
+          __builtin_amdgcn_sqrtf(__double2float_ru(mx * mx + my * my + mz * mz)) * 1.000001f;
+        const float left = slack > 0.f ? slack - 2.000001f * mv - 1e-30f
+                                       : -slack - 1.000001f * mv - 1e-30f;
+        if (left > 0.f)
+        {
+          cert[q] = (slack > 0.f ? left : -left) * 0.9999999f;
+          active = false;
+        }
+      }
+    }
+    if (__ballot(active) == 0ull)
+      continue; // every query of the block went through
 
     d3 x = mk(0.0, 0.0, 0.0);
     float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f, tauf = 0.f;
@@ -1190,13 +1304,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     // ubq: squared centroid distance behind ubf; rpf: square root of prunef, rounded up
     float boundf = FLT_MAX, ubf = FLT_MAX, prunef = FLT_MAX, bboxf = active ? INFINITY : -1.f;
     float ubq = FLT_MAX, rpf = 1.9e19f;
+    float sec2 = INFINITY, minraw = INFINITY, minlin = INFINITY; // for the certificate
+    float widen = 0.f; // margin by which the walk looks farther (widen_of)
     int cnt = 0, npend = 0, phead = 0; // queue: npend entries from slot phead on, oldest first
     int32_t hs_used = -1;
 
     auto retighten = [&]() {
       // (the hardware's square root is within one unit in the last place: the factors
       // cover it)
-      const float r = __builtin_amdgcn_sqrtf(ubf) * 1.000001f + tauf;
+      const float r = __builtin_amdgcn_sqrtf(ubf) * 1.000001f + tauf + widen;
       prunef = fminf(boundf, r * r * 1.000001f);
       rpf = __builtin_amdgcn_sqrtf(prunef) * 1.000001f;
       const float rb_ = rpf + 1.7320509f * eabs; // as box_bound, from the root already at hand
@@ -1209,7 +1325,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         cnt = 0; // every older contender was above the old minimum
       best = nb;
       bound = nbound;
-      boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
+      const double rw = r + (double)widen; // (turned away beyond the widened bound)
+      boundf = fminf(fmaxf(__double2float_ru(rw * rw), FLT_MIN), FLT_MAX);
       retighten();
     };
     auto screen_one = [&]() { // the oldest queued triangle (nearest leaves come first), if
@@ -1218,12 +1335,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
       phead++;
       npend--;
       const int32_t s = pend_s[slot][lane];
-      if (__uint_as_float((uint32_t)pend_lb[slot][lane] << 16) <= prunef)
+      const float lbq = __uint_as_float((uint32_t)pend_lb[slot][lane] << 16);
+      if (lbq > prunef)
+        sec2 = fminf(sec2, lbq); // dropped against the tighter bound: at least that far
+      else
       {
         STAT(3, 1);
         d3 P0, P1, P2;
         load_tri(a.tverts, s, P0, P1, P2);
         const double d2 = tri_d2_screen(x, P0, P1, P2);
+        // whichever of this triangle and the best so far loses is one of "the others"
+        sec2 = fminf(sec2, __double2float_rd(fmax(d2, best)) * 0.999999f);
         if (d2 < best)
           set_best(d2);
         if (d2 <= bound)
@@ -1245,6 +1367,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
       eabs = smax * 2.3841858e-07f * 1.0000002f;
       tau = 1e-9 * (double)smax;
       tauf = 1.0000001e-9f * smax;
+      widen = CERT ? widen_of(a, T, a.qpos + 3 * q, x, eabs) : 0.f;
       if (a.cap2 < 1e300)
         set_best(a.cap2);
       int32_t hs = a.use_hint ? a.hint[q] : -1;
@@ -1331,6 +1454,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         lb1 = box_d2(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf);
         m0 = __ballot(lb0 <= bboxf);
         m1 = __ballot(lb1 <= bboxf);
+        minraw = fminf(minraw, fminf(lb0 <= bboxf ? INFINITY : lb0, lb1 <= bboxf ? INFINITY : lb1));
       }
       else
       {
@@ -1344,6 +1468,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         m1 = __ballot(lb1 <= bboxf);
         m2 = __ballot(lb2 <= bboxf);
         m3 = __ballot(lb3 <= bboxf);
+        minraw = fminf(minraw,
+          fminf(fminf(lb0 <= bboxf ? INFINITY : lb0, lb1 <= bboxf ? INFINITY : lb1),
+            fminf(lb2 <= bboxf ? INFINITY : lb2, lb3 <= bboxf ? INFINITY : lb3)));
       }
       const unsigned long long many = m0 | m1 | m2 | m3;
       uint32_t next = 0;
@@ -1377,6 +1504,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
             k3 = 0xffffffffu;
             const float lbc = c == 0u ? lb0 : c == 1u ? lb1 : c == 2u ? lb2 : lb3;
             const bool want = lbc <= bboxf;
+            if (!want)
+              minraw = fminf(minraw, lbc); // (the bound may have shrunk since the node's visit)
             if (__ballot(want) == 0ull)
               continue;
             STAT(1, lane == 0 ? 1 : 0);
@@ -1416,11 +1545,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
               }
               const float reach = rpf + rb.w + 3.f * eabs;
               const bool near = want && q2 * 0.999998f <= reach * reach * 1.000001f;
+              if (want && !near) // turned away by its centroid: at least this far
+                minlin = fminf(minlin, __builtin_amdgcn_sqrtf(q2) * 0.999999f - (rb.w + 3.f * eabs));
               if (__ballot(near) == 0ull)
                 continue;
               float lb, ub;
               tri_bounds_rec<true>(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, xf, yf, zf, eabs,
                 lb, ub);
+              if (near && lb > prunef)
+                sec2 = fminf(sec2, lb); // turned away by the plane-and-circle bound
               if (near && lb <= prunef && (int32_t)(s0 + t) != hs_used)
               {
                 const int slot = (phead + npend) & (PENDW - 1);
@@ -1474,6 +1607,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     const bool ovf = active && cnt > RING3;
     if (active && !tie && !ovf)
       a.hint[q] = (cnt == 1) ? ring[0][lane] : -1;
+    if (active && cert)
+      cert[q] = make_certificate(cnt, best, sec2, minraw, minlin, tau, eabs, a.cap2);
     const unsigned long long mt = __ballot(tie);
     if (mt)
     {

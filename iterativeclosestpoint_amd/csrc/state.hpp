@@ -20,6 +20,7 @@ struct RunState
   // ---- the shortcut's certificates (local.hpp): the transform they were last brought up
   // to date for (rows 0..2), and whether they are up to date at all
   double cert_T[12];
+  double cert_cap2; // the cap (squared) the far certificates were made for
   int32_t cert_ok;
   int32_t pad_;
 };
