@@ -1328,7 +1328,10 @@ static void note_pass(icpx_ctx* c, double n, double mean, double fallback, bool 
   c->bad_streak = bad ? c->bad_streak + 1 : 0;
   if (!bad && c->local_holdoff == 0)
     c->probation = false;
-  if (c->bad_streak >= (c->probation ? 1 : 2) && c->local_holdoff == 0)
+  // (with certificates the first passes of the shortcut leave most queries to the tree and
+  // later ones only those without a certificate: it gets four passes to show that)
+  const int patience = c->use_cert ? 4 : 2;
+  if (c->bad_streak >= (c->probation ? 1 : patience) && c->local_holdoff == 0)
   {
     c->local_holdoff = c->holdoff_len;
     c->holdoff_len = c->holdoff_len < 64 ? 2 * c->holdoff_len : 64;
@@ -1504,6 +1507,7 @@ static int run_search3(icpx_ctx* c)
     wide.scene_max = c->scene_max;
     wide.cap2 = c->cap2;
     wide.cert = a.cert;
+    wide.widen = a.cert ? a.widen_max : 0.f;
     widep = &wide;
   }
   if (L == 1)
@@ -1564,6 +1568,7 @@ static int run_search(icpx_ctx* c)
     a.scene_max = c->scene_max;
     a.cap2 = c->cap2;
     a.cert = nullptr;
+    a.widen = 0.f;
     ScopedTimer tm(c, 0);
     switch (G)
     {

@@ -305,7 +305,10 @@ struct Search2Args
   int use_hint;
   float scene_max; // largest |coordinate| of the target's bounds
   double cap2;     // square of the distance beyond which nothing needs to be found (DBL_MAX: none)
-  float* cert;     // certificates (see local.hpp): a query settled here gets none (0); or null
+  float* cert;     // certificates (see local.hpp), or null: a query that ends here with nothing
+                   // within the cap gets a far certificate, any other none (0)
+  float widen;     // margin by which the walk looks beyond its bound, so that a far certificate
+                   // is worth something (0 when certificates are not kept)
 };
 
 template <int G>
@@ -347,6 +350,7 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
   bool flushed = false;
   int32_t hs_used = -1; // the hinted triangle already sits in the ring
   int top = 0;
+  float minlb = INFINITY; // smallest lower bound (squared) of anything this lane turned away
 
   auto set_best = [&](double nb) {
     // older ring entries were all above the old minimum; if the new bound is
@@ -356,7 +360,8 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
       cnt = 0;
     best = nb;
     bound = nbound;
-    boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
+    const double rw = sqrt(nb) + tau + (double)a.widen; // (boxes are turned away beyond this)
+    boundf = fminf(fmaxf(__double2float_ru(rw * rw), FLT_MIN), FLT_MAX);
   };
 
   // exact evaluation of the ring's entries, folded into (ed2, eid, es)
@@ -432,7 +437,10 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
       const unsigned long long e = stack[g][--top];
       const float lbf = __uint_as_float((uint32_t)(e >> 32));
       if (lbf > boundf)
+      {
+        minlb = fminf(minlb, lbf);
         continue;
+      }
       const uint32_t n = (uint32_t)e;
       if (n >= first_leaf)
       {
@@ -446,6 +454,8 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
       const float dz = fmaxf(fmaxf(fmaxf(b1.x - zf, zf - b2.y), 0.f) - eabs, 0.f);
       const float lb = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * 0.99999952f;
       const bool push = lb <= boundf; // an empty box gives +inf and boundf is finite
+      if (!push)
+        minlb = fminf(minlb, lb);
       // distinct integer keys: the bound's bits, lowered by G ulps, with the lane number in
       // the low bits (so the stored bound never exceeds the computed one)
       const uint32_t lbits = __float_as_uint(lb);
@@ -472,6 +482,8 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
       load_tri(a.tverts, s, P0, P1, P2);
       d2 = tri_d2_screen(x, P0, P1, P2);
     }
+    if (d2 < INFINITY)
+      minlb = fminf(minlb, __double2float_rd(d2) * 0.999999f);
     const double m = group_min<G>(d2);
     if (m < best)
       set_best(m);
@@ -509,11 +521,22 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
         resolve();
       win = es;
     }
+    // nothing within the cap: everything was turned away or screened beyond it, and the
+    // nearest of those bounds says by how much
+    float far = 0.f;
+    if (a.cert && cnt == 0 && !flushed && a.cap2 < 1e300)
+    {
+      const float m2 = (float)group_min<G>((double)minlb);
+      const float capd = __double2float_ru(sqrt(a.cap2));
+      const float c = __builtin_amdgcn_sqrtf(m2) * 0.999999f - capd * 1.000001f - 2.1f * (float)tau -
+        fminf(eabs, 0.2f * eabs * eabs / fmaxf(capd, 1e-30f));
+      far = (c > 0.f && c < 1e30f) ? -c : 0.f;
+    }
     if (j == 0)
     {
       a.hint[q] = win;
       if (a.cert)
-        a.cert[q] = 0.f;
+        a.cert[q] = far;
     }
   }
 }

@@ -825,6 +825,48 @@ def test_certificate_is_below_the_true_gap(icpx, synth):
     assert worst <= 1.0 + 1e-9
 
 
+def test_tree_and_far_certificates_are_sound(icpx, synth, oracle):
+    """Certificates made by the tree kernels, for a cloud that is mostly off the surface and
+    partly beyond the distance threshold: a positive one never exceeds the brute-force gap
+    between the nearest and the second nearest triangle, a negative one never exceeds the
+    distance by which the nearest triangle is beyond the threshold; and the rows of every pass
+    equal the oracle's and those of the library with certificates off."""
+    xyz, tri = synth.bumpy_torus(48, 24)
+    pts, f, fn = synth.sample_surface(xyz, tri, 40_000, seed=41)
+    off = np.stack([synth.gaussian(9, 90 + 2 * k, len(pts)) for k in range(3)], -1)
+    scale = 10.0 ** (-5 + 4.5 * synth.u01(9, 97, len(pts)))        # 1e-5 .. 0.3 off the surface
+    src = (pts.astype(np.float64) + off * scale[:, None]).astype(np.float32)
+    cap = 0.05
+    mesh = oracle.Mesh(xyz, tri)
+    ctx, plain = icpx.Context(0), icpx.Context(0)
+    for c_, local in ((ctx, 1), (plain, 0)):
+        c_.set_group_width(1)
+        c_.set_local(local)
+        c_.set_target(xyz, tri)
+        c_.set_source(src)
+    T = synth.rigid(rz=0.01, t=(1e-4, 0, 0))
+    for k, m in enumerate((0, 1e-3, 1e-5, 1e-6, 1e-7, 1e-6, 1e-7, 1e-8)):
+        T = synth.rigid(rx=3 * m, t=(0, m, -m)) @ T
+        rows = ctx.correspond(T, step=1, max_dist=cap)
+        check_rows(rows, plain.correspond(T, step=1, max_dist=cap))
+        if k in (0, 3, 7):
+            check_rows(rows, mesh.correspond(src, T=T, step=1, max_dist=cap, grid=True))
+        ctx.accumulate(1, T, step=1, max_dist=cap)
+        plain.accumulate(1, T, step=1, max_dist=cap)
+    cert = ctx.debug_certificates(len(src))
+    order = ctx.debug_query_order(len(src))
+    assert (cert > 0).mean() > 0.3 and (cert < 0).mean() > 0.1
+    P = xyz[tri].astype(np.float64)
+    x = src.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    for k0 in range(0, 40_000, 8000):
+        pos = np.arange(k0, k0 + 400)
+        d = np.sort(_point_triangle_dist(x[order[pos]], P), axis=1)
+        near, far = cert[pos] > 0, cert[pos] < 0
+        assert np.all(cert[pos][near] <= (d[:, 1] - d[:, 0])[near] + 1e-12)
+        assert np.all(d[:, 0][near | (cert[pos] == 0)] >= 0)
+        assert np.all(-cert[pos][far] <= d[:, 0][far] - cap + 1e-12)
+
+
 def _sharded_rank(rank, world, port, metric, out):
     """One rank of test_sharded_device_loop_two_ranks (spawned)."""
     import torch.distributed as dist
