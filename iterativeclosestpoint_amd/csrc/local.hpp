@@ -245,7 +245,12 @@ constexpr int LOCAL_PEND = 6;   // triangles a lane may hold for the screening l
 // slack: as long as the query has moved by less than half of it since (distances to a
 // triangle change by at most the move), w is still the only contender, and the search
 // would return it again.  Later passes only subtract twice the move from the slack of such
-// a query and leave its hint alone; the search runs again when the slack is used up.
+// a query and leave its hint alone; the search runs again when the slack is used up.  The
+// tree kernels make certificates the same way from what they turned away
+// (make_certificate in search3.hpp), including negative ones for queries with nothing
+// within the distance cap (the nearest bound less the cap; such a query has no winner and
+// stays so while its move is below that).  Every certificate, whoever made it, is checked
+// here; what fails the check and cannot be settled from a list goes to the tree kernel.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_search_local(LocalArgs la)
 {
   const Search3Args& a = la.s;
