@@ -223,7 +223,10 @@ extern "C"
    * contender also keeps a certificate: a lower bound of how much farther every other
    * triangle is, less the tie tolerance; while twice its accumulated move stays below that,
    * later passes keep its winner without searching (a search would return it again).
-   * 2 = the shortcut without certificates.  0 = always walk the tree.  Same results. */
+   * 2 = the shortcut without certificates.  0 = always walk the tree.  3 = as 1, with the
+   * certificates checked by a light kernel of their own and the shortcut run over the
+   * queries that failed (what 1 does by itself for clouds of four million points and more,
+   * where the extra launch pays).  Same results. */
   int icpx_set_local(icpx_ctx* ctx, int enable);
 
   /* Tree kernel of the lane-per-query path.  4 (default) = by regime: a whole pass over a

@@ -161,6 +161,12 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
   publish_record(s, rec, seq);
 }
 
+// From this many queries on, a pass that finds certificates checks them in a kernel of its
+// own (k_certify) and runs the shortcut over the rest; below, the extra launch costs more
+// than the lighter shortcut pass saves (measured: +6 % at a million queries, -8 % of the
+// search time at sixteen million).
+constexpr int64_t CERTIFY_MIN = 4000000;
+
 struct icpx_ctx
 {
   int device = 0;
@@ -213,6 +219,9 @@ struct icpx_ctx
   int holdoff_len = 8;   // length of the next suspension: doubles each time one is called for
   bool after_cold = false; // the last pass was a cold one
   int since_cold = 0;      // passes since the last cold one
+  uint32_t* d_work = nullptr;  // queries whose certificates failed (k_certify's list)
+  bool certs_live = false;     // the last pass kept certificates for this one to check
+  int64_t certify_min = CERTIFY_MIN; // clouds from this size have their certificates checked by k_certify
   bool pass_certs = false; // the pass being enqueued keeps every query's certificate up to date
   double cap2 = DBL_MAX;   // this pass's distance threshold, squared (what the searches stop at)
   bool probation = false; // back from a suspension: one more bad pass suspends it again
@@ -451,6 +460,7 @@ static void free_queries(icpx_ctx* c)
   dev_free(&c->d_ovf_best);
   dev_free(&c->d_fallback);
   dev_free(&c->d_cert);
+  dev_free(&c->d_work);
   c->q_cap = 0;
   c->q3_cap = 0;
   c->prep_step = -1;
@@ -737,6 +747,7 @@ extern "C" int icpx_set_local(icpx_ctx* c, int enable)
     return fail(ICPX_E_INVALID, "null context");
   c->use_local = enable ? 1 : 0;
   c->use_cert = enable == 2 ? 0 : 1; // 2: the shortcut without its certificates
+  c->certify_min = enable == 3 ? 0 : CERTIFY_MIN; // 3: certificates checked by their own kernel at any size
   c->local_holdoff = 0; // (and the policy starts afresh)
   c->bad_streak = 0;
   c->holdoff_len = 8;
@@ -1392,8 +1403,9 @@ static int run_search3(icpx_ctx* c)
   {
     ALLOC(c->d_cand, c->nq * RING3);
     ALLOC(c->d_tie_list, c->nq);
-    ALLOC(c->d_counters, 8);
+    ALLOC(c->d_counters, 12);
     c->counters_clean = false;
+    ALLOC(c->d_work, c->nq);
     ALLOC(c->d_ovf_list, c->nq);
     ALLOC(c->d_ovf_best, c->nq);
     ALLOC(c->d_fallback, c->nq);
@@ -1451,7 +1463,7 @@ static int run_search3(icpx_ctx* c)
   a.cert = c->pass_certs ? c->d_cert : nullptr;
   ScopedTimer tm(c, 0);
   if (!c->counters_clean)
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 12 * sizeof(uint32_t), st));
   c->counters_clean = false;
   if (use_local)
   {
@@ -1469,7 +1481,36 @@ static int run_search3(icpx_ctx* c)
     la.cert_T = c->d_state->cert_T;
     la.cert_ok = &c->d_state->cert_ok;
     la.cert_cap2 = &c->d_state->cert_cap2;
-    k_search_local<<<grid, 256, 0, st>>>(la);
+    la.work = nullptr;
+    la.work_count = nullptr;
+    unsigned lgrid = grid;
+    // a large cloud with certificates from the last pass: those are checked by a light
+    // kernel of their own, and the shortcut serves the ones that failed
+    if (a.cert && c->certs_live && a.use_hint && c->certify_min >= 0 && c->nq >= c->certify_min)
+    {
+      CertifyArgs ca;
+      ca.qpos = c->d_qpos;
+      ca.nq = c->nq;
+      ca.cert = c->d_cert;
+      ca.T = a.T.T;
+      ca.stop = a.T.stop;
+      ca.cert_T = la.cert_T;
+      ca.cert_ok = la.cert_ok;
+      ca.cert_cap2 = la.cert_cap2;
+      ca.cap2 = c->cap2;
+      ca.work = c->d_work;
+      ca.work_count = c->d_counters + 8;
+      k_certify<<<grid, 256, 0, st>>>(ca);
+      la.work = c->d_work;
+      la.work_count = c->d_counters + 8;
+      const unsigned cap = (unsigned)c->num_cus * 16u; // four resident rounds of blocks
+      if (lgrid > cap)
+        lgrid = cap;
+    }
+    if (la.work)
+      k_search_local<true><<<lgrid, 256, 0, st>>>(la);
+    else
+      k_search_local<false><<<lgrid, 256, 0, st>>>(la);
     a.qlist = c->d_fallback; // the tree kernel serves what is left,
     a.use_hint = 1;          // starting from the triangles the shortcut reached
     c->local_passes++;
@@ -1538,6 +1579,7 @@ static void set_cap(icpx_ctx* c, double max_dist)
 static int run_search(icpx_ctx* c)
 {
   c->last_local = false;
+  c->certs_live = c->pass_certs && c->hint_valid; // (what the last pass left)
   c->pass_certs = false;
   const int G = pick_width(c);
   if (G == 1)

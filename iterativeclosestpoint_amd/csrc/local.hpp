@@ -224,6 +224,10 @@ struct LocalArgs
   const double* cert_T;
   const int32_t* cert_ok;
   const double* cert_cap2; // the cap the far certificates were made for
+  // a pass whose certificates were already checked (k_certify) serves the listed queries
+  // only: work[0 .. *work_count); null: every query
+  const uint32_t* work;
+  const uint32_t* work_count;
 };
 
 constexpr int LOCAL_STEPS = 16; // moves along the surface before a query is given up
@@ -251,6 +255,7 @@ constexpr int LOCAL_PEND = 6;   // triangles a lane may hold for the screening l
 // within the distance cap (the nearest bound less the cap; such a query has no winner and
 // stays so while its move is below that).  Every certificate, whoever made it, is checked
 // here; what fails the check and cannot be settled from a list goes to the tree kernel.
+template <bool LISTED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_search_local(LocalArgs la)
 {
   const Search3Args& a = la.s;
@@ -259,11 +264,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   // long as its chain of dependent reads
   Xf T, Tc;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int64_t q = (int64_t)blockIdx.x * 256 + tid;
-  const bool active = q < a.nq;
-  const int64_t qc = active ? q : 0;
-  const float p3[3] = { a.qpos[3 * qc], a.qpos[3 * qc + 1], a.qpos[3 * qc + 2] };
-  const float slack0 = a.cert ? a.cert[qc] : 0.f;
+  const uint32_t totalv = LISTED ? *la.work_count : (uint32_t)a.nq;
+  // (a whole pass: one round per block, and the query's own reads join the others)
+  const int64_t q0 = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t qc0 = (!LISTED && q0 < a.nq) ? q0 : 0;
+  float p30[3] = { 0.f, 0.f, 0.f }, slack00 = 0.f;
+  if (!LISTED)
+  {
+    p30[0] = a.qpos[3 * qc0];
+    p30[1] = a.qpos[3 * qc0 + 1];
+    p30[2] = a.qpos[3 * qc0 + 2];
+    slack00 = a.cert ? a.cert[qc0] : 0.f;
+  }
   const int32_t stopv = a.T.stop ? *a.T.stop : 0;
   int32_t okv = 0;
 #pragma unroll
@@ -293,7 +305,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   __shared__ uint32_t wcount[4];
   __shared__ uint32_t bbase;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int64_t total = (int64_t)__builtin_amdgcn_readfirstlane(totalv);
 
+  // (a listed pass runs a bounded grid over however many the list turned out to hold)
+  int64_t first = (int64_t)blockIdx.x * 256;
+  if (first >= total)
+    return;
+  do
+  {
+  const bool active = first + tid < total;
+  const int64_t q = !active ? 0 : LISTED ? (int64_t)la.work[first + tid] : first + tid;
+  float p3[3] = { p30[0], p30[1], p30[2] };
+  if (LISTED)
+  {
+    p3[0] = a.qpos[3 * q];
+    p3[1] = a.qpos[3 * q + 1];
+    p3[2] = a.qpos[3 * q + 2];
+  }
+  const float slack0 = slack00;
   d3 x = mk(0.0, 0.0, 0.0);
   float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f;
   double tau = 0.0, best = DBL_MAX, bound = DBL_MAX;
@@ -304,7 +333,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   int32_t hs = -1;
   bool local = false, certified = false;
   float sec2 = 0.f; // lower bound of the squared distance of every triangle but the best
-  const bool cert_on = a.cert && a.use_hint && __builtin_amdgcn_readfirstlane(okv) != 0;
+  // (the listed queries are the ones whose certificates failed)
+  const bool cert_on = a.cert && !LISTED && a.use_hint && __builtin_amdgcn_readfirstlane(okv) != 0;
   // far certificates hold for the cap they were made for, or a smaller one
   const bool far_on = cert_on && a.cap2 <= uniform_f64(capv) * (1.0 + 1e-12);
 
@@ -582,6 +612,98 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
       a.ovf_best[q] = best;
       a.ovf_list[base + __popcll(mo & lt)] = (uint32_t)q;
     }
+  }
+  if (!LISTED)
+    break;
+  __syncthreads(); // (the rings and counts are reused by the next round)
+  first += (int64_t)gridDim.x * 256;
+  } while (first < total);
+}
+
+// The certificate check of k_search_local on its own, one light lane per query: a pass in
+// which nearly every query stands on its certificate is then a short streaming kernel, and
+// the search kernel (whose registers allow few wavefronts per CU) runs over the list of
+// those that do not.
+struct CertifyArgs
+{
+  const float* qpos;
+  int64_t nq;
+  float* cert;
+  const double* T;
+  const int32_t* stop;
+  const double* cert_T;
+  const int32_t* cert_ok;
+  const double* cert_cap2;
+  double cap2;
+  uint32_t* work;       // queries the search kernel has to look at, in block order
+  uint32_t* work_count; // (zero on entry; the pass's reduction leaves it so)
+};
+
+__global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
+{
+  Xf T, Tc;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t q = (int64_t)blockIdx.x * 256 + tid;
+  const bool active = q < c.nq;
+  const int64_t qc = active ? q : 0;
+  const float p3[3] = { c.qpos[3 * qc], c.qpos[3 * qc + 1], c.qpos[3 * qc + 2] };
+  const float slack = c.cert[qc];
+  const int32_t stopv = c.stop ? *c.stop : 0;
+  const int32_t okv = *c.cert_ok;
+  const double capv = *c.cert_cap2;
+#pragma unroll
+  for (int i = 0; i < 12; i++)
+  {
+    T.m[i] = c.T[i];
+    Tc.m[i] = c.cert_T[i];
+  }
+  if (__builtin_amdgcn_readfirstlane(stopv) != 0)
+    return;
+#pragma unroll
+  for (int i = 0; i < 12; i++)
+  {
+    T.m[i] = uniform_f64(T.m[i]);
+    Tc.m[i] = uniform_f64(Tc.m[i]);
+  }
+  __shared__ uint32_t wcount[4];
+  __shared__ uint32_t bbase;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const bool cert_on = __builtin_amdgcn_readfirstlane(okv) != 0;
+  const bool far_on = cert_on && c.cap2 <= uniform_f64(capv) * (1.0 + 1e-12);
+  bool certified = false;
+  if (active && cert_on && (slack > 0.f || (slack < 0.f && far_on)))
+  {
+    // (the same arithmetic as in k_search_local)
+    const d3 x = xform(T, p3);
+    const d3 xp = xform(Tc, p3);
+    const double mx = x.x - xp.x, my = x.y - xp.y, mz = x.z - xp.z;
+    const float m2 = __double2float_ru(mx * mx + my * my + mz * mz);
+    const float mv = __builtin_amdgcn_sqrtf(m2) * 1.000001f;
+    const float left = slack > 0.f ? slack - 2.000001f * mv - 1e-30f
+                                   : -slack - 1.000001f * mv - 1e-30f;
+    if (left > 0.f)
+    {
+      certified = true;
+      c.cert[q] = (slack > 0.f ? left : -left) * 0.9999999f;
+    }
+  }
+  const bool todo = active && !certified;
+  const unsigned long long mf = __ballot(todo);
+  if (lane == 0)
+    wcount[tid >> 6] = (uint32_t)__popcll(mf);
+  __syncthreads();
+  if (tid == 0)
+  {
+    const uint32_t tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    bbase = tot ? atomicAdd(c.work_count, tot) : 0u;
+  }
+  __syncthreads();
+  if (todo)
+  {
+    uint32_t pos = bbase + (uint32_t)__popcll(mf & lt);
+    for (int w = 0; w < (tid >> 6); w++)
+      pos += wcount[w];
+    c.work[pos] = (uint32_t)q;
   }
 }
 

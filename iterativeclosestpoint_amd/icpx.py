@@ -164,7 +164,8 @@ class Context:
         _chk(load().icpx_synchronize(self._h))
 
     def set_local(self, enable=True):
-        """True/1: the shortcut with certificates; 2: without certificates; False/0: tree only."""
+        """True/1: the shortcut with certificates; 2: without certificates; 3: as 1, the
+        certificates always checked by their own kernel; False/0: tree only."""
         _chk(load().icpx_set_local(self._h, int(enable)))
 
     def debug_stats(self):

@@ -705,7 +705,9 @@ def test_shortcut_on_triangle_soup(icpx, synth, oracle, seed):
     q[:50] = fan_c + np.array([0, 0, 1.0]) * np.linspace(1e-6, 0.2, 50)[:, None]  # above the fan
     q = q.astype(np.float32)
     ctxs = []
-    modes = (1, 0, 2)  # shortcut with certificates, tree only, shortcut without certificates
+    # shortcut with certificates, tree only, shortcut without certificates, shortcut with the
+    # certificates checked by their own kernel (what large clouds get)
+    modes = (1, 0, 2, 3)
     for local in modes:
         c_ = icpx.Context(0)
         c_.set_group_width(1)
@@ -742,7 +744,7 @@ def test_certificates_change_nothing(icpx, synth, oracle):
     src = (pts.astype(np.float64) + off * scale[:, None]).astype(np.float32)
     mesh = oracle.Mesh(xyz, tri)
     ctxs = []
-    for local in (1, 2, 0):
+    for local in (1, 2, 0, 3):  # (3: the certificates checked by their own kernel)
         c_ = icpx.Context(0)
         c_.set_group_width(1)
         c_.set_local(local)
@@ -757,11 +759,14 @@ def test_certificates_change_nothing(icpx, synth, oracle):
         rows = [c_.correspond(T, step=1, max_dist=10.0) for c_ in ctxs]
         check_rows(rows[0], rows[1])
         check_rows(rows[0], rows[2])
+        check_rows(rows[0], rows[3])
         if i in (0, 3, 7, 11, 15):
             check_rows(rows[0], mesh.correspond(src, T=T, step=1, max_dist=10.0, grid=True))
         sums = [c_.accumulate(1, T, step=1, max_dist=10.0) for c_ in ctxs]  # and a fused pass
         assert np.array_equal(sums[0], sums[1]) and np.array_equal(sums[0], sums[2])
+        assert np.array_equal(sums[0], sums[3])
         kept.append(float((ctxs[0].debug_certificates(len(src)) > 0).mean()))
+        assert np.array_equal(ctxs[0].debug_certificates(len(src)), ctxs[3].debug_certificates(len(src)))
     assert ctxs[0].debug_stats()["local_passes"] >= 20
     assert min(kept[2:8]) > 0.9 and kept[-1] > 0.9  # most queries hold a certificate
 
@@ -838,8 +843,8 @@ def test_tree_and_far_certificates_are_sound(icpx, synth, oracle):
     src = (pts.astype(np.float64) + off * scale[:, None]).astype(np.float32)
     cap = 0.05
     mesh = oracle.Mesh(xyz, tri)
-    ctx, plain = icpx.Context(0), icpx.Context(0)
-    for c_, local in ((ctx, 1), (plain, 0)):
+    ctx, plain, listed = icpx.Context(0), icpx.Context(0), icpx.Context(0)
+    for c_, local in ((ctx, 1), (plain, 0), (listed, 3)):
         c_.set_group_width(1)
         c_.set_local(local)
         c_.set_target(xyz, tri)
@@ -849,11 +854,14 @@ def test_tree_and_far_certificates_are_sound(icpx, synth, oracle):
         T = synth.rigid(rx=3 * m, t=(0, m, -m)) @ T
         rows = ctx.correspond(T, step=1, max_dist=cap)
         check_rows(rows, plain.correspond(T, step=1, max_dist=cap))
+        check_rows(rows, listed.correspond(T, step=1, max_dist=cap))
         if k in (0, 3, 7):
             check_rows(rows, mesh.correspond(src, T=T, step=1, max_dist=cap, grid=True))
         ctx.accumulate(1, T, step=1, max_dist=cap)
         plain.accumulate(1, T, step=1, max_dist=cap)
+        listed.accumulate(1, T, step=1, max_dist=cap)
     cert = ctx.debug_certificates(len(src))
+    assert np.array_equal(cert, listed.debug_certificates(len(src)))
     order = ctx.debug_query_order(len(src))
     assert (cert > 0).mean() > 0.3 and (cert < 0).mean() > 0.1
     P = xyz[tri].astype(np.float64)
