@@ -9,7 +9,7 @@ from iterativeclosestpoint_amd import icpx, synth  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "c4s"
 c = {"c4s": lambda: synth.config_c4(nu=500, nv=400, npts=640_000),
-     "c3": synth.config_c3,
+     "c3": synth.config_c3, "c4": synth.config_c4,
      "c5big": lambda: synth.config_c5(nu=1000, nv=500, npts=1_200_000)}[which]()
 ctx = icpx.Context(0)
 ctx.set_target(c["target_xyz"], c["target_tri"])
@@ -30,5 +30,8 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 14):
         it, s_ms - ps, (cert > 0).mean(), (cert < 0).mean(),
         float(np.median(cert[cert > 0])) if (cert > 0).any() else 0.0, float(np.median(mv)),
         ctx.debug_counters(), ctx.debug_stats()["local_passes"]), flush=True)
+    if (cert > 0).any():
+        print("       slack quantiles 1%% %.2e  3%% %.2e  10%% %.2e;  no certificate %.4f" % (
+            *np.quantile(cert[cert > 0], [0.01, 0.03, 0.1]), (cert == 0).mean()), flush=True)
     ps = s_ms
     T = Tn

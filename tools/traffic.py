@@ -11,7 +11,7 @@ import csv
 import json
 import sys
 
-SEARCH = ("k_search", "k_contested")
+SEARCH = ("k_search", "k_contested", "k_fallback", "k_certify")
 
 
 def per_pass(path, counter):
