@@ -222,7 +222,10 @@ extern "C"
    * walking the tree; the rest still walk it.  A query settled that way with a single
    * contender also keeps a certificate: a lower bound of how much farther every other
    * triangle is, less the tie tolerance; while twice its accumulated move stays below that,
-   * later passes keep its winner without searching (a search would return it again).
+   * later passes keep its winner without searching (a search would return it again).  A
+   * query with several contenders at the same distance (on an edge or a vertex) keeps the
+   * set of them the same way: while the certificate lasts only the exact evaluation of
+   * those few is repeated.
    * 2 = the shortcut without certificates.  0 = always walk the tree.  3 = as 1, with the
    * certificates checked by a light kernel of their own and the shortcut run over the
    * queries that failed (what 1 does by itself for clouds of four million points and more,
@@ -260,8 +263,12 @@ extern "C"
    * query); 4: {shortcut passes, tree-only passes, neighbour-list builds, list radius x
    * 1e9, list entries} (5 x int64); 5: the shortcut's certificates (float per query of
    * this shard: how far the query may still move before its winner is looked at again,
-   * 0 = none); 6: the library's query order (int32 per query: position -> kept index
-   * within the shard; arrays 0 and 5 are in this order). */
+   * 0 = none, negative = how far before something may come within the distance threshold;
+   * a positive value whose last mantissa bit is set stands for a set of contenders rather
+   * than a single winner); 6: the library's query order (int32 per query: position -> kept
+   * index within the shard; arrays 0, 5 and 7 are in this order); 7: the contender sets
+   * (8 x int32 per query, Morton positions, -1 ends a shorter set; meaningful for queries
+   * whose certificate stands for a set). */
   int icpx_debug_dump(icpx_ctx* ctx, int what, void* out, int64_t count);
 
   /* Forget the winners of the previous search pass.  A pass normally starts each

@@ -712,6 +712,11 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
     src = c->d_qk;
     bytes = sizeof(int32_t) * (size_t)std::min<int64_t>(count, c->nq);
   }
+  else if (what == 7 && c->d_cand)
+  {
+    src = c->d_cand; // RING3 entries per query (count = number of entries)
+    bytes = sizeof(int32_t) * (size_t)std::min<int64_t>(count, c->nq * RING3);
+  }
   if (!src)
     return fail(ICPX_E_INVALID, "nothing to dump");
   HIPCHK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
@@ -1500,7 +1505,10 @@ static int run_search3(icpx_ctx* c)
       ca.cap2 = c->cap2;
       ca.work = c->d_work;
       ca.work_count = c->d_counters + 8;
-      k_certify<<<grid, 256, 0, st>>>(ca);
+      ca.cand = c->d_cand;
+      ca.tie_list = c->d_tie_list;
+      ca.counters = c->d_counters;
+      k_certify<<<nblk(c->nq, 256 * CERTIFY_ROUNDS), 256, 0, st>>>(ca);
       la.work = c->d_work;
       la.work_count = c->d_counters + 8;
       const unsigned cap = (unsigned)c->num_cus * 16u; // four resident rounds of blocks

@@ -331,8 +331,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   const float ginv2 = la.grid.inv_step * la.grid.inv_step * 1.00001f;
   int cnt = 0;
   int32_t hs = -1;
-  bool local = false, certified = false;
-  float sec2 = 0.f; // lower bound of the squared distance of every triangle but the best
+  bool local = false, certified = false, certset = false;
+  float sec2 = 0.f; // lower bound of the squared distance of every triangle outside the ring
   // (the listed queries are the ones whose certificates failed)
   const bool cert_on = a.cert && !LISTED && a.use_hint && __builtin_amdgcn_readfirstlane(okv) != 0;
   // far certificates hold for the cap they were made for, or a smaller one
@@ -373,8 +373,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                                      : -slack - 1.000001f * mv - 1e-30f;
       if (left > 0.f)
       {
-        certified = true;
-        a.cert[q] = (slack > 0.f ? left : -left) * 0.9999999f;
+        const bool sc = cert_is_set(slack);
+        const float keep = slack > 0.f ? cert_encode(left * 0.9999999f, sc) : -left * 0.9999999f;
+        a.cert[q] = keep;
+        certified = keep != 0.f;
+        certset = sc && certified;
       }
     }
     hs = (a.use_hint && !certified) ? a.hint[q] : -1;
@@ -486,6 +489,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     }
   }
 
+  // (a query that stands on a set certificate has its contenders weighed again)
+  if (!LISTED)
+    push_certified_sets(certset, q, a.cand, a.tie_list, a.counters, lane, lt);
+
   // The list is taken eight entries at a time: the indices, then their boxes, are in
   // flight together (the loads of one entry depend on each other, those of different
   // entries do not).  Entries whose boxes pass meet the edge half-spaces; the few that
@@ -498,8 +505,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     d3 P0, P1, P2;
     load_tri(a.tverts, s, P0, P1, P2);
     const double d2 = tri_d2_screen(x, P0, P1, P2);
-    // whichever of this triangle and the best so far loses is one of "the others"
-    sec2 = fminf(sec2, __double2float_rd(fmax(d2, best)) * 0.999999f);
+    sec2 = note_screened(sec2, d2, best, bound, tau, cnt);
     if (d2 < best)
       set_best(d2);
     if (d2 <= bound)
@@ -556,13 +562,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   if (a.cert && active && !certified && local)
   {
     float slack = 0.f;
-    if (local && cnt == 1)
+    if (local && cnt >= 1 && cnt <= RING3)
     {
       const float dw = __double2float_ru(sqrt(best));
       slack = __builtin_amdgcn_sqrtf(sec2) * 0.999999f - dw * 1.000001f - 2.1f * (float)tau -
         fminf(eabs, 0.2f * eabs * eabs / fmaxf(dw, 1e-30f)); // (see make_certificate)
     }
-    a.cert[q] = fmaxf(slack, 0.f);
+    a.cert[q] = cert_encode(slack, cnt >= 2);
   }
 
 #ifdef ICPX_STATS
@@ -594,8 +600,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     if (tie)
     {
       for (int i = 0; i < RING3; i++)
-        if (i < cnt)
-          a.cand[q * RING3 + i] = ring[i][tid];
+        if (i <= cnt)
+          a.cand[q * RING3 + i] = i < cnt ? ring[i][tid] : -1;
       a.tie_list[base + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
     }
   }
@@ -637,17 +643,19 @@ struct CertifyArgs
   double cap2;
   uint32_t* work;       // queries the search kernel has to look at, in block order
   uint32_t* work_count; // (zero on entry; the pass's reduction leaves it so)
+  const int32_t* cand;  // where the sets of the set certificates are kept, and the pass's
+  uint2* tie_list;      // tie list and counters, which such queries join
+  uint32_t* counters;
 };
+
+// (atomics on one address go through at some 10 ns apiece, so a block takes many queries
+// and appends to each list once)
+constexpr int CERTIFY_ROUNDS = 16;
 
 __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
 {
   Xf T, Tc;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int64_t q = (int64_t)blockIdx.x * 256 + tid;
-  const bool active = q < c.nq;
-  const int64_t qc = active ? q : 0;
-  const float p3[3] = { c.qpos[3 * qc], c.qpos[3 * qc + 1], c.qpos[3 * qc + 2] };
-  const float slack = c.cert[qc];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t stopv = c.stop ? *c.stop : 0;
   const int32_t okv = *c.cert_ok;
   const double capv = *c.cert_cap2;
@@ -665,45 +673,93 @@ __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
     T.m[i] = uniform_f64(T.m[i]);
     Tc.m[i] = uniform_f64(Tc.m[i]);
   }
-  __shared__ uint32_t wcount[4];
-  __shared__ uint32_t bbase;
+  // per round and wavefront: queries for the work list / for the tie list; then their
+  // exclusive prefix sums in the same order
+  __shared__ uint32_t wcount[CERTIFY_ROUNDS * 4], scount[CERTIFY_ROUNDS * 4];
+  __shared__ uint32_t bbase, sbase;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const bool cert_on = __builtin_amdgcn_readfirstlane(okv) != 0;
   const bool far_on = cert_on && c.cap2 <= uniform_f64(capv) * (1.0 + 1e-12);
-  bool certified = false;
-  if (active && cert_on && (slack > 0.f || (slack < 0.f && far_on)))
+  const int64_t first = (int64_t)blockIdx.x * (256 * CERTIFY_ROUNDS) + tid;
+  uint32_t todo_bits = 0, set_bits = 0;
+#pragma unroll 4
+  for (int k = 0; k < CERTIFY_ROUNDS; k++)
   {
-    // (the same arithmetic as in k_search_local)
-    const d3 x = xform(T, p3);
-    const d3 xp = xform(Tc, p3);
-    const double mx = x.x - xp.x, my = x.y - xp.y, mz = x.z - xp.z;
-    const float m2 = __double2float_ru(mx * mx + my * my + mz * mz);
-    const float mv = __builtin_amdgcn_sqrtf(m2) * 1.000001f;
-    const float left = slack > 0.f ? slack - 2.000001f * mv - 1e-30f
-                                   : -slack - 1.000001f * mv - 1e-30f;
-    if (left > 0.f)
+    const int64_t q = first + (int64_t)k * 256;
+    const bool active = q < c.nq;
+    const int64_t qc = active ? q : 0;
+    const float p3[3] = { c.qpos[3 * qc], c.qpos[3 * qc + 1], c.qpos[3 * qc + 2] };
+    const float slack = c.cert[qc];
+    bool certified = false, certset = false;
+    if (active && cert_on && (slack > 0.f || (slack < 0.f && far_on)))
     {
-      certified = true;
-      c.cert[q] = (slack > 0.f ? left : -left) * 0.9999999f;
+      // (the same arithmetic as in k_search_local)
+      const d3 x = xform(T, p3);
+      const d3 xp = xform(Tc, p3);
+      const double mx = x.x - xp.x, my = x.y - xp.y, mz = x.z - xp.z;
+      const float m2 = __double2float_ru(mx * mx + my * my + mz * mz);
+      const float mv = __builtin_amdgcn_sqrtf(m2) * 1.000001f;
+      const float left = slack > 0.f ? slack - 2.000001f * mv - 1e-30f
+                                     : -slack - 1.000001f * mv - 1e-30f;
+      if (left > 0.f)
+      {
+        const bool sc = cert_is_set(slack);
+        const float keep = slack > 0.f ? cert_encode(left * 0.9999999f, sc) : -left * 0.9999999f;
+        c.cert[q] = keep;
+        certified = keep != 0.f;
+        certset = sc && certified;
+      }
+    }
+    const bool todo = active && !certified;
+    todo_bits |= (todo ? 1u : 0u) << k;
+    set_bits |= (certset ? 1u : 0u) << k;
+    const unsigned long long mf = __ballot(todo), ms = __ballot(certset);
+    if (lane == 0)
+    {
+      wcount[k * 4 + wave] = (uint32_t)__popcll(mf);
+      scount[k * 4 + wave] = (uint32_t)__popcll(ms);
     }
   }
-  const bool todo = active && !certified;
-  const unsigned long long mf = __ballot(todo);
-  if (lane == 0)
-    wcount[tid >> 6] = (uint32_t)__popcll(mf);
   __syncthreads();
-  if (tid == 0)
+  if (tid < 2)
   {
-    const uint32_t tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
-    bbase = tot ? atomicAdd(c.work_count, tot) : 0u;
+    // (one lane per list: 64 counts to their exclusive prefix sums, one atomic)
+    uint32_t* cnts = tid == 0 ? wcount : scount;
+    uint32_t run = 0;
+    for (int i = 0; i < CERTIFY_ROUNDS * 4; i++)
+    {
+      const uint32_t v = cnts[i];
+      cnts[i] = run;
+      run += v;
+    }
+    const uint32_t base = run ? atomicAdd(tid == 0 ? c.work_count : &c.counters[0], run) : 0u;
+    if (tid == 0)
+      bbase = base;
+    else
+      sbase = base;
   }
   __syncthreads();
-  if (todo)
+  for (int k = 0; k < CERTIFY_ROUNDS; k++)
   {
-    uint32_t pos = bbase + (uint32_t)__popcll(mf & lt);
-    for (int w = 0; w < (tid >> 6); w++)
-      pos += wcount[w];
-    c.work[pos] = (uint32_t)q;
+    const int64_t q = first + (int64_t)k * 256;
+    const bool todo = (todo_bits >> k) & 1u, certset = (set_bits >> k) & 1u;
+    const unsigned long long mf = __ballot(todo), ms = __ballot(certset);
+    if (todo)
+      c.work[bbase + wcount[k * 4 + wave] + (uint32_t)__popcll(mf & lt)] = (uint32_t)q;
+    if (certset)
+    {
+      // (a query that stands on a set certificate has its contenders weighed again: they are
+      // in cand[] already, -1 ends a set of fewer than RING3)
+      const int4 c0 = *reinterpret_cast<const int4*>(c.cand + q * RING3);
+      const int4 c1 = *reinterpret_cast<const int4*>(c.cand + q * RING3 + 4);
+      const int32_t m[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        cnt += (cnt == i && m[i] >= 0) ? 1 : 0;
+      c.tie_list[sbase + scount[k * 4 + wave] + (uint32_t)__popcll(ms & lt)] =
+        make_uint2((uint32_t)q, (uint32_t)cnt);
+    }
   }
 }
 

@@ -223,33 +223,92 @@ __device__ __forceinline__ float widen_of(const Search3Args& a, const Xf& T, con
   return fminf(fmaxf(8.f * mv, 2.f * eabs), fmaxf(a.widen_max, 2.f * eabs));
 }
 
-// The certificate of a finished query.  cnt: contenders; best: the winner's screened squared
-// distance; sec2: lower bound of the squared distance of every other triangle that was
-// screened; minraw: smallest raw squared box distance (box_d2) among the boxes turned away;
+constexpr int RING3 = 8;
+
+// A positive certificate's last mantissa bit says what stands while it lasts: 0, the single
+// winner; 1, the set of contenders kept in cand[] (a query on an edge or a vertex shared by
+// several triangles has them at the same distance for good): the winner among them is
+// worked out anew every pass by exact evaluation, but no search is needed to know that
+// nobody else is in the race.  (The value gives way by up to two units in the last place.)
+__device__ __forceinline__ float cert_encode(float c, bool set)
+{
+  const uint32_t b = __float_as_uint(c);
+  if (!(c > 0.f) || b < 8u)
+    return 0.f;
+  return __uint_as_float(((b - 2u) & ~1u) | (set ? 1u : 0u));
+}
+__device__ __forceinline__ bool cert_is_set(float c)
+{
+  return c > 0.f && (__float_as_uint(c) & 1u) != 0u;
+}
+
+// The queries of a wavefront that stand on a set certificate join the pass's tie list; their
+// contenders are in cand[] already (-1 ends a set of fewer than RING3).
+__device__ __forceinline__ void push_certified_sets(bool isset, int64_t q, const int32_t* cand,
+  uint2* tie_list, uint32_t* counters, int lane, unsigned long long lt)
+{
+  const unsigned long long mt = __ballot(isset);
+  if (!mt)
+    return;
+  const int leader = __ffsll((long long)mt) - 1;
+  uint32_t base = 0;
+  if (lane == leader)
+    base = atomicAdd(&counters[0], (uint32_t)__popcll(mt));
+  base = __shfl(base, leader, 64);
+  if (isset)
+  {
+    const int4 c0 = *reinterpret_cast<const int4*>(cand + q * RING3);
+    const int4 c1 = *reinterpret_cast<const int4*>(cand + q * RING3 + 4);
+    const int32_t m[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      cnt += (cnt == i && m[i] >= 0) ? 1 : 0;
+    tie_list[base + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
+  }
+}
+
+// The certificate of a finished query.  cnt: contenders (1: a single winner; 2..RING3: a set,
+// all in the ring); best: the winner's screened squared distance; sec2: lower bound of the
+// squared distance of every screened triangle that is not (or no longer) in the ring;
+// minraw: smallest raw squared box distance (box_d2) among the boxes turned away;
 // minlin: smallest lower bound, as a distance, of triangles turned away by cheap bounds.
 __device__ __forceinline__ float make_certificate(int cnt, double best, float sec2, float minraw,
   float minlin, double tau, float eabs, double cap2)
 {
+  const bool near = cnt >= 1 && cnt <= RING3;
   // (a raw box distance exceeds the true one by at most sqrt(3) eabs)
   const float dbox = __builtin_amdgcn_sqrtf(minraw) * 0.999999f - 1.7320509f * eabs;
   const float others = fminf(fminf(dbox, minlin), __builtin_amdgcn_sqrtf(sec2) * 0.999999f);
   // what the screened distance of the winner may be off by: a few units in the last place
   // of the squared coordinates, i.e. ~0.02 eabs^2 / distance, never more than eabs
-  const float dw = __double2float_ru(sqrt(cnt == 1 ? best : cap2));
+  const float dw = __double2float_ru(sqrt(near ? best : cap2));
   const float slop = fminf(eabs, 0.2f * eabs * eabs / fmaxf(dw, 1e-30f)) + 2.1f * (float)tau;
   float c = 0.f;
-  if (cnt == 1)
+  if (near)
     c = others - dw * 1.000001f - slop;
   else if (cnt == 0 && cap2 < 1e300)
     c = -(others - dw * 1.000001f - slop);
   // (a near certificate must be positive, a far one negative; infinities mean nothing was
   // ever turned away, which only a mesh without triangles does)
-  if (cnt == 1)
-    return (c > 0.f && c < 1e30f) ? c : 0.f;
+  if (near)
+    return (c > 0.f && c < 1e30f) ? cert_encode(c, cnt >= 2) : 0.f;
   return (c < 0.f && c > -1e30f) ? c : 0.f;
 }
 
-constexpr int RING3 = 8;
+// A screened triangle joins the bookkeeping of the certificate: one that is turned away is
+// at least its distance away; a new minimum that empties the ring leaves contenders behind
+// that were at least the old minimum away.  (Call before set_best / the ring's update.)
+__device__ __forceinline__ float note_screened(float sec2, double d2, double best, double bound,
+  double tau, int cnt)
+{
+  if (d2 < best)
+  {
+    const double r = sqrt(d2) + tau;
+    return (r * r < best && cnt > 0) ? fminf(sec2, __double2float_rd(best) * 0.999999f) : sec2;
+  }
+  return d2 <= bound ? sec2 : fminf(sec2, __double2float_rd(d2) * 0.999999f);
+}
 
 // fp32 lower bound of the squared distance to a box; never above the true value
 __device__ __forceinline__ float box_lb(float lox, float loy, float loz, float hix, float hiy,
@@ -614,8 +673,8 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
         if (tie)
         {
           for (int i = 0; i < RING3; i++)
-            if (i < cnt)
-              a.cand[q * RING3 + i] = ring[i][tid];
+            if (i <= cnt)
+              a.cand[q * RING3 + i] = i < cnt ? ring[i][tid] : -1;
           a.tie_list[base + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
         }
       }
@@ -785,10 +844,9 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
           d3 P0, P1, P2;
           load_tri(a.tverts, s, P0, P1, P2);
           const double d2 = tri_d2_screen(x, P0, P1, P2);
-          // whichever of this triangle and the best so far loses is one of "the others"
-          // (the start triangle, met again, is the best or has lost already)
+          // (the start triangle, met again, is in the ring or has lost already)
           if ((int32_t)s != hs_used)
-            sec2 = fminf(sec2, __double2float_rd(fmax(d2, best)) * 0.999999f);
+            sec2 = note_screened(sec2, d2, best, bound, tau, cnt);
           if (d2 < best)
             set_best(d2);
           if (d2 <= bound && (int32_t)s != hs_used)
@@ -995,8 +1053,8 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
         if (tie)
         {
           for (int i = 0; i < RING3; i++)
-            if (i < cnt)
-              a.cand[q * RING3 + i] = ring[i][tid];
+            if (i <= cnt)
+              a.cand[q * RING3 + i] = i < cnt ? ring[i][tid] : -1;
           a.tie_list[base + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
         }
       }
@@ -1272,6 +1330,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     bool active = idx < total;
     const int64_t q = active ? (a.qlist ? (int64_t)a.qlist[idx] : idx) : 0;
     const float slack = (cert_on && active) ? cert[q] : 0.f;
+    bool isset = false;
     if (__ballot(slack != 0.f) != 0ull)
     {
       // as in k_search_local: a query whose certificate covers its move keeps its result
@@ -1290,10 +1349,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
                                        : -slack - 1.000001f * mv - 1e-30f;
         if (left > 0.f)
         {
-          cert[q] = (slack > 0.f ? left : -left) * 0.9999999f;
-          active = false;
+          isset = cert_is_set(slack);
+          const float keep = slack > 0.f ? cert_encode(left * 0.9999999f, isset) : -left * 0.9999999f;
+          cert[q] = keep;
+          // (a set certificate worn down to nothing: the search runs after all)
+          isset = isset && keep > 0.f;
+          active = !(keep != 0.f);
         }
       }
+      push_certified_sets(isset, q, a.cand, a.tie_list, a.counters, lane, lt);
     }
     if (__ballot(active) == 0ull)
       continue; // every query of the block went through
@@ -1347,8 +1411,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         d3 P0, P1, P2;
         load_tri(a.tverts, s, P0, P1, P2);
         const double d2 = tri_d2_screen(x, P0, P1, P2);
-        // whichever of this triangle and the best so far loses is one of "the others"
-        sec2 = fminf(sec2, __double2float_rd(fmax(d2, best)) * 0.999999f);
+        sec2 = note_screened(sec2, d2, best, bound, tau, cnt);
         if (d2 < best)
           set_best(d2);
         if (d2 <= bound)
@@ -1623,8 +1686,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
       if (tie)
       {
         for (int i = 0; i < RING3; i++)
-          if (i < cnt)
-            a.cand[q * RING3 + i] = ring[i][lane];
+          if (i <= cnt)
+            a.cand[q * RING3 + i] = i < cnt ? ring[i][lane] : -1;
         a.tie_list[tb + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
       }
     }

@@ -193,6 +193,19 @@ class Context:
         _chk(load().icpx_debug_dump(self._h, 6, _p(v), int(n)))
         return v
 
+    def debug_cell_ids(self, nt):
+        """Morton position of a triangle -> its cell id (-1 - id for a degenerate one)."""
+        v = np.zeros(int(nt), np.int32)
+        _chk(load().icpx_debug_dump(self._h, 1, _p(v), int(nt)))
+        return v
+
+    def debug_contender_sets(self, n):
+        """(n, 8) Morton positions of the contenders kept for the first n queries (in the
+        library's order); -1 ends a shorter set."""
+        v = np.zeros((int(n), 8), np.int32)
+        _chk(load().icpx_debug_dump(self._h, 7, _p(v), int(n) * 8))
+        return v
+
     def set_persistent(self, enable=True):
         _chk(load().icpx_set_persistent(self._h, int(enable)))
 

@@ -821,13 +821,30 @@ def test_certificate_is_below_the_true_gap(icpx, synth):
     P = xyz[tri].astype(np.float64)
     x = src.astype(np.float64) @ T2[:3, :3].T + T2[:3, 3]  # as the kernels transform: in fp64
     worst = 0.0
-    for k0 in range(0, 4000, 500):  # a sample of the queries, in chunks
-        pos = np.arange(k0 * 10, k0 * 10 + 500)
-        d = np.sort(_point_triangle_dist(x[order[pos]], P), axis=1)
+    isset = (cert > 0) & ((cert.view(np.uint32) & 1) == 1)  # stands for a set of contenders
+    sets = ctx.debug_contender_sets(len(src))
+    cell = ctx.debug_cell_ids(len(tri))
+    nsets = 0
+    # a sample of the queries, in chunks, and every query that stands on a set
+    chunks = [np.arange(k0 * 10, k0 * 10 + 500) for k0 in range(0, 4000, 500)]
+    chunks.append(np.nonzero(isset)[0][:400])
+    for pos in chunks:
+        dall = _point_triangle_dist(x[order[pos]], P)
+        d = np.sort(dall, axis=1)
         gap = d[:, 1] - d[:, 0]
+        for i in np.nonzero(isset[pos])[0]:
+            # a set certificate: the gap to the nearest triangle outside the set
+            members = sets[pos[i]]
+            members = members[:np.argmax(members < 0)] if (members < 0).any() else members
+            assert 2 <= len(members) <= 8
+            out = np.ones(len(P), bool)
+            out[cell[members]] = False
+            gap[i] = dall[i][out].min() - d[i, 0]
+            nsets += 1
         assert np.all(cert[pos] <= gap + 1e-12), "a certificate exceeds the true gap"
         worst = max(worst, float((cert[pos] / np.maximum(gap, 1e-300)).max()))
     assert worst <= 1.0 + 1e-9
+    assert isset.sum() > 0 and nsets > 0  # (points sampled on the surface: some lie on edges)
 
 
 def test_tree_and_far_certificates_are_sound(icpx, synth, oracle):
@@ -870,6 +887,7 @@ def test_tree_and_far_certificates_are_sound(icpx, synth, oracle):
         pos = np.arange(k0, k0 + 400)
         d = np.sort(_point_triangle_dist(x[order[pos]], P), axis=1)
         near, far = cert[pos] > 0, cert[pos] < 0
+        near &= (cert[pos].view(np.uint32) & 1) == 0  # (set certificates: tested elsewhere)
         assert np.all(cert[pos][near] <= (d[:, 1] - d[:, 0])[near] + 1e-12)
         assert np.all(d[:, 0][near | (cert[pos] == 0)] >= 0)
         assert np.all(-cert[pos][far] <= d[:, 0][far] - cap + 1e-12)
