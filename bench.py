@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--width", type=int, default=0, help="lanes per query (0 = library default)")
     ap.add_argument("--leaf", type=int, default=0, help="triangles per leaf (0 = library default)")
+    ap.add_argument("--local", type=int, default=-1,
+                    help="shortcut mode (icpx_set_local); -1 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl",
                     help="process-group backend (gloo + --one-device rehearses N ranks on one GPU)")
@@ -120,6 +122,8 @@ def main():
         sh.ctx.set_group_width(args.width)
     if args.leaf:
         sh.ctx.set_leaf_size(args.leaf)
+    if args.local >= 0:
+        sh.ctx.set_local(args.local)
     sh.set_target(c["target_xyz"], c["target_tri"])
     sh.set_source(c["source_xyz"], c["source_normals"])
     origin = sh.ctx.origin

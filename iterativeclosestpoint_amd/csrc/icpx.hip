@@ -166,6 +166,9 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
 // than the lighter shortcut pass saves (measured: +6 % at a million queries, -8 % of the
 // search time at sixteen million).
 constexpr int64_t CERTIFY_MIN = 4000000;
+// pass counters: {ties, overflows, pool position, shortcut fallbacks}, the last pass's copy
+// of the four, then (from word 16) the segment counts of k_certify's list
+constexpr int PASS_COUNTERS = 16 + CERTIFY_SEGS * CERTIFY_SEG_STRIDE;
 
 struct icpx_ctx
 {
@@ -1408,9 +1411,9 @@ static int run_search3(icpx_ctx* c)
   {
     ALLOC(c->d_cand, c->nq * RING3);
     ALLOC(c->d_tie_list, c->nq);
-    ALLOC(c->d_counters, 12);
+    ALLOC(c->d_counters, PASS_COUNTERS);
     c->counters_clean = false;
-    ALLOC(c->d_work, c->nq);
+    ALLOC(c->d_work, c->nq + CERTIFY_SEGS * 256 * CERTIFY_ROUNDS);
     ALLOC(c->d_ovf_list, c->nq);
     ALLOC(c->d_ovf_best, c->nq);
     ALLOC(c->d_fallback, c->nq);
@@ -1468,7 +1471,7 @@ static int run_search3(icpx_ctx* c)
   a.cert = c->pass_certs ? c->d_cert : nullptr;
   ScopedTimer tm(c, 0);
   if (!c->counters_clean)
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, 12 * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, PASS_COUNTERS * sizeof(uint32_t), st));
   c->counters_clean = false;
   if (use_local)
   {
@@ -1488,6 +1491,7 @@ static int run_search3(icpx_ctx* c)
     la.cert_cap2 = &c->d_state->cert_cap2;
     la.work = nullptr;
     la.work_count = nullptr;
+    la.segcap = 0;
     unsigned lgrid = grid;
     // a large cloud with certificates from the last pass: those are checked by a light
     // kernel of their own, and the shortcut serves the ones that failed
@@ -1504,14 +1508,18 @@ static int run_search3(icpx_ctx* c)
       ca.cert_cap2 = la.cert_cap2;
       ca.cap2 = c->cap2;
       ca.work = c->d_work;
-      ca.work_count = c->d_counters + 8;
-      ca.cand = c->d_cand;
-      ca.tie_list = c->d_tie_list;
-      ca.counters = c->d_counters;
-      k_certify<<<nblk(c->nq, 256 * CERTIFY_ROUNDS), 256, 0, st>>>(ca);
+      ca.work_count = c->d_counters + 16;
+      // (a few thousand blocks, each appending once to its segment)
+      ca.rounds = (int)std::min<int64_t>(std::max<int64_t>(c->nq / (256 * 2048), 1), CERTIFY_ROUNDS);
+      const unsigned cgrid = nblk(c->nq, 256 * ca.rounds);
+      ca.segcap = (int64_t)((cgrid + CERTIFY_SEGS - 1) / CERTIFY_SEGS) * 256 * ca.rounds;
+      k_certify<<<cgrid, 256, 0, st>>>(ca);
       la.work = c->d_work;
-      la.work_count = c->d_counters + 8;
-      const unsigned cap = (unsigned)c->num_cus * 16u; // four resident rounds of blocks
+      la.work_count = c->d_counters + 16;
+      la.segcap = ca.segcap;
+      // (a multiple of the number of segments; four resident rounds of blocks at most)
+      lgrid = (lgrid + CERTIFY_SEGS - 1) / CERTIFY_SEGS * CERTIFY_SEGS;
+      const unsigned cap = (unsigned)c->num_cus * 16u / CERTIFY_SEGS * CERTIFY_SEGS;
       if (lgrid > cap)
         lgrid = cap;
     }

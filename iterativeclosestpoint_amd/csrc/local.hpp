@@ -225,9 +225,10 @@ struct LocalArgs
   const int32_t* cert_ok;
   const double* cert_cap2; // the cap the far certificates were made for
   // a pass whose certificates were already checked (k_certify) serves the listed queries
-  // only: work[0 .. *work_count); null: every query
+  // only (see CertifyArgs for the list's layout); null: every query
   const uint32_t* work;
   const uint32_t* work_count;
+  int64_t segcap;
 };
 
 constexpr int LOCAL_STEPS = 16; // moves along the surface before a query is given up
@@ -264,7 +265,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   // long as its chain of dependent reads
   Xf T, Tc;
   const int tid = threadIdx.x, lane = tid & 63;
-  const uint32_t totalv = LISTED ? *la.work_count : (uint32_t)a.nq;
+  // (a listed pass: block b serves segment b mod CERTIFY_SEGS, together with every
+  // CERTIFY_SEGS-th other block)
+  const int seg = LISTED ? (int)(blockIdx.x % CERTIFY_SEGS) : 0;
+  const uint32_t totalv = LISTED ? la.work_count[seg * CERTIFY_SEG_STRIDE] : (uint32_t)a.nq;
   // (a whole pass: one round per block, and the query's own reads join the others)
   const int64_t q0 = (int64_t)blockIdx.x * 256 + tid;
   const int64_t qc0 = (!LISTED && q0 < a.nq) ? q0 : 0;
@@ -308,13 +312,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   const int64_t total = (int64_t)__builtin_amdgcn_readfirstlane(totalv);
 
   // (a listed pass runs a bounded grid over however many the list turned out to hold)
-  int64_t first = (int64_t)blockIdx.x * 256;
+  int64_t first = (int64_t)(LISTED ? blockIdx.x / CERTIFY_SEGS : blockIdx.x) * 256;
   if (first >= total)
     return;
+  const uint32_t* const work = LISTED ? la.work + seg * la.segcap : nullptr;
   do
   {
   const bool active = first + tid < total;
-  const int64_t q = !active ? 0 : LISTED ? (int64_t)la.work[first + tid] : first + tid;
+  const uint32_t entry = (LISTED && active) ? work[first + tid] : 0u;
+  const int64_t q = !active ? 0 : LISTED ? (int64_t)(entry & 0x7fffffffu) : first + tid;
   float p3[3] = { p30[0], p30[1], p30[2] };
   if (LISTED)
   {
@@ -331,7 +337,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   const float ginv2 = la.grid.inv_step * la.grid.inv_step * 1.00001f;
   int cnt = 0;
   int32_t hs = -1;
-  bool local = false, certified = false, certset = false;
+  // (a listed query with the top bit set passed the check and stands on a set certificate)
+  bool local = false, certified = (entry >> 31) != 0u, certset = certified;
   float sec2 = 0.f; // lower bound of the squared distance of every triangle outside the ring
   // (the listed queries are the ones whose certificates failed)
   const bool cert_on = a.cert && !LISTED && a.use_hint && __builtin_amdgcn_readfirstlane(okv) != 0;
@@ -490,8 +497,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   }
 
   // (a query that stands on a set certificate has its contenders weighed again)
-  if (!LISTED)
-    push_certified_sets(certset, q, a.cand, a.tie_list, a.counters, lane, lt);
+  push_certified_sets(certset, q, a.cand, a.tie_list, a.counters, lane, lt);
 
   // The list is taken eight entries at a time: the indices, then their boxes, are in
   // flight together (the loads of one entry depend on each other, those of different
@@ -622,7 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   if (!LISTED)
     break;
   __syncthreads(); // (the rings and counts are reused by the next round)
-  first += (int64_t)gridDim.x * 256;
+  first += (int64_t)(gridDim.x / CERTIFY_SEGS) * 256;
   } while (first < total);
 }
 
@@ -641,15 +647,18 @@ struct CertifyArgs
   const int32_t* cert_ok;
   const double* cert_cap2;
   double cap2;
-  uint32_t* work;       // queries the search kernel has to look at, in block order
-  uint32_t* work_count; // (zero on entry; the pass's reduction leaves it so)
-  const int32_t* cand;  // where the sets of the set certificates are kept, and the pass's
-  uint2* tie_list;      // tie list and counters, which such queries join
-  uint32_t* counters;
+  // The list of queries the search kernel has to look at comes in CERTIFY_SEGS segments of
+  // segcap entries, each with a count of its own (work_count[s * CERTIFY_SEG_STRIDE]; zero on
+  // entry, the pass's reduction leaves them so): block b appends to segment b mod
+  // CERTIFY_SEGS.  Atomics on one address go through at some 10 ns apiece, which a single
+  // count would make the length of this kernel.  An entry with the top bit set passed the
+  // check but stands on a set certificate: the search kernel puts it on the tie list.
+  uint32_t* work;
+  uint32_t* work_count;
+  int64_t segcap;
+  int rounds; // queries per block / 256 (1 .. CERTIFY_ROUNDS)
 };
 
-// (atomics on one address go through at some 10 ns apiece, so a block takes many queries
-// and appends to each list once)
 constexpr int CERTIFY_ROUNDS = 16;
 
 __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
@@ -675,15 +684,15 @@ __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
   }
   // per round and wavefront: queries for the work list / for the tie list; then their
   // exclusive prefix sums in the same order
-  __shared__ uint32_t wcount[CERTIFY_ROUNDS * 4], scount[CERTIFY_ROUNDS * 4];
-  __shared__ uint32_t bbase, sbase;
+  __shared__ uint32_t wcount[CERTIFY_ROUNDS * 4];
+  __shared__ uint32_t bbase;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const bool cert_on = __builtin_amdgcn_readfirstlane(okv) != 0;
   const bool far_on = cert_on && c.cap2 <= uniform_f64(capv) * (1.0 + 1e-12);
-  const int64_t first = (int64_t)blockIdx.x * (256 * CERTIFY_ROUNDS) + tid;
+  const int rounds = c.rounds;
+  const int64_t first = (int64_t)blockIdx.x * (256 * rounds) + tid;
   uint32_t todo_bits = 0, set_bits = 0;
-#pragma unroll 4
-  for (int k = 0; k < CERTIFY_ROUNDS; k++)
+  for (int k = 0; k < rounds; k++)
   {
     const int64_t q = first + (int64_t)k * 256;
     const bool active = q < c.nq;
@@ -711,55 +720,36 @@ __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
       }
     }
     const bool todo = active && !certified;
-    todo_bits |= (todo ? 1u : 0u) << k;
+    todo_bits |= ((todo || certset) ? 1u : 0u) << k;
     set_bits |= (certset ? 1u : 0u) << k;
-    const unsigned long long mf = __ballot(todo), ms = __ballot(certset);
+    const unsigned long long mf = __ballot(todo || certset);
     if (lane == 0)
-    {
       wcount[k * 4 + wave] = (uint32_t)__popcll(mf);
-      scount[k * 4 + wave] = (uint32_t)__popcll(ms);
-    }
   }
   __syncthreads();
-  if (tid < 2)
+  const int seg = (int)(blockIdx.x % CERTIFY_SEGS);
+  if (tid == 0)
   {
-    // (one lane per list: 64 counts to their exclusive prefix sums, one atomic)
-    uint32_t* cnts = tid == 0 ? wcount : scount;
+    // (the counts to their exclusive prefix sums, one atomic)
     uint32_t run = 0;
-    for (int i = 0; i < CERTIFY_ROUNDS * 4; i++)
+    for (int i = 0; i < rounds * 4; i++)
     {
-      const uint32_t v = cnts[i];
-      cnts[i] = run;
+      const uint32_t v = wcount[i];
+      wcount[i] = run;
       run += v;
     }
-    const uint32_t base = run ? atomicAdd(tid == 0 ? c.work_count : &c.counters[0], run) : 0u;
-    if (tid == 0)
-      bbase = base;
-    else
-      sbase = base;
+    bbase = run ? atomicAdd(&c.work_count[seg * CERTIFY_SEG_STRIDE], run) : 0u;
   }
   __syncthreads();
-  for (int k = 0; k < CERTIFY_ROUNDS; k++)
+  uint32_t* const work = c.work + seg * c.segcap;
+  for (int k = 0; k < rounds; k++)
   {
     const int64_t q = first + (int64_t)k * 256;
-    const bool todo = (todo_bits >> k) & 1u, certset = (set_bits >> k) & 1u;
-    const unsigned long long mf = __ballot(todo), ms = __ballot(certset);
-    if (todo)
-      c.work[bbase + wcount[k * 4 + wave] + (uint32_t)__popcll(mf & lt)] = (uint32_t)q;
-    if (certset)
-    {
-      // (a query that stands on a set certificate has its contenders weighed again: they are
-      // in cand[] already, -1 ends a set of fewer than RING3)
-      const int4 c0 = *reinterpret_cast<const int4*>(c.cand + q * RING3);
-      const int4 c1 = *reinterpret_cast<const int4*>(c.cand + q * RING3 + 4);
-      const int32_t m[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
-      int cnt = 0;
-#pragma unroll
-      for (int i = 0; i < 8; i++)
-        cnt += (cnt == i && m[i] >= 0) ? 1 : 0;
-      c.tie_list[sbase + scount[k * 4 + wave] + (uint32_t)__popcll(ms & lt)] =
-        make_uint2((uint32_t)q, (uint32_t)cnt);
-    }
+    const bool listed = (todo_bits >> k) & 1u;
+    const unsigned long long mf = __ballot(listed);
+    if (listed)
+      work[bbase + wcount[k * 4 + wave] + (uint32_t)__popcll(mf & lt)] =
+        (uint32_t)q | (((set_bits >> k) & 1u) << 31);
   }
 }
 

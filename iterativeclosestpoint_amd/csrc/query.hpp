@@ -519,8 +519,8 @@ __device__ __forceinline__ bool reduce_partials_body(
     if (stat && l == 3)
       stat[2] = (double)old; // shortcut fallbacks of this pass
   }
-  if (counters && i == 0 && l == 4)
-    counters[8] = 0u; // the length of the list of queries whose certificates failed
+  if (counters && i == 0 && l < 32)
+    counters[16 + l * 64] = 0u; // the lengths of the segments of k_certify's list
   if (stat && !counters && i == 0 && l == 0)
     stat[2] = 0.0;
   double v = 0.0;

@@ -242,6 +242,11 @@ __device__ __forceinline__ bool cert_is_set(float c)
   return c > 0.f && (__float_as_uint(c) & 1u) != 0u;
 }
 
+// The list of queries whose certificates failed (k_certify) is kept in this many segments,
+// with counts this many words apart.
+constexpr int CERTIFY_SEGS = 32;
+constexpr int CERTIFY_SEG_STRIDE = 64;
+
 // The queries of a wavefront that stand on a set certificate join the pass's tie list; their
 // contenders are in cand[] already (-1 ends a set of fewer than RING3).
 __device__ __forceinline__ void push_certified_sets(bool isset, int64_t q, const int32_t* cand,
