@@ -1323,12 +1323,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
   unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0;
 #endif
 
+  // (the first 64 queries of a wavefront are its own by its number, later ones come off
+  // the pool behind those: thousands of wavefronts drawing at once would queue at the
+  // counter, some 10 ns apiece)
+  bool own = true;
   while (true)
   {
-    uint32_t base = 0;
-    if (lane == 0)
-      base = atomicAdd(&a.counters[2], 64u);
-    base = uni32(base);
+    uint32_t base = blockIdx.x * 64u;
+    if (!own)
+    {
+      if (lane == 0)
+        base = atomicAdd(&a.counters[2], 64u) + gridDim.x * 64u;
+      base = uni32(base);
+    }
+    own = false;
     if ((int64_t)base >= total)
       break;
     const int64_t idx = (int64_t)base + lane;
