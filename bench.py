@@ -208,8 +208,8 @@ def main():
                 "bound": "hbm",
                 "kernel": "k_search",
                 "kernel_note": "one launch = the search kernels of one pass on the library's "
-                               "stream (k_search_local or k_search3w, then k_search3p and "
-                               "k_contested), HIP events around them",
+                               "stream (k_certify for large clouds, k_search_local or k_search3w, "
+                               "then k_fallback / k_search3p and k_contested), HIP events around them",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

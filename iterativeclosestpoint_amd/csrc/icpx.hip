@@ -1258,7 +1258,8 @@ static void launch_search3(const Search3Args& a, unsigned grid, unsigned pgrid, 
   unsigned rgrid = grid / 8 + 1;
   if (rgrid > 2048)
     rgrid = 2048;
-  k_contested<L><<<rgrid + grid, 256, 0, st>>>(a, rgrid);
+  // (overflows are rare: a bounded number of blocks takes them in turns)
+  k_contested<L><<<rgrid + std::min(grid, 256u), 256, 0, st>>>(a, rgrid);
 }
 
 // Neighbour lists of every leaf of the one-triangle-per-leaf tree for radius eps (see

@@ -898,10 +898,12 @@ constexpr uint32_t FALLBACK_SMALL = ICPX_FALLBACK_SMALL;
 template <int L>
 __global__ __launch_bounds__(256) void k_fallback(Search3Args a, Search2Args w)
 {
+  const uint32_t total = a.counters[3];
+  if (total == 0u)
+    return; // (most converged passes: gone after one read)
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
-  const uint32_t total = a.counters[3];
   if (total > FALLBACK_SMALL)
   {
     search3p_body<L>(a, T);
@@ -1770,10 +1772,23 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
 template <int L>
 __global__ __launch_bounds__(256) void k_contested(Search3Args a, unsigned rblocks)
 {
+  // (the counts first: in most passes most of these blocks have nothing to do and should
+  // be gone after one read)
   if (blockIdx.x < rblocks)
-    resolve_ties_body(a, blockIdx.x, rblocks);
+  {
+    if (blockIdx.x * 32u < a.counters[0])
+      resolve_ties_body(a, blockIdx.x, rblocks);
+  }
   else
-    search3_body<L, true>(a, blockIdx.x - rblocks);
+  {
+    const uint32_t novf = a.counters[1];
+    const unsigned nover = gridDim.x - rblocks;
+    for (unsigned b = blockIdx.x - rblocks; (uint64_t)b * 256u < novf; b += nover)
+    {
+      search3_body<L, true>(a, b);
+      __syncthreads(); // (the ring in LDS is reused)
+    }
+  }
 }
 
 } // namespace icpx
