@@ -78,6 +78,15 @@ extern "C"
   int icpx_set_target(icpx_ctx* ctx, const float* xyz, int64_t nv, const int32_t* tri, int64_t nt,
     const float* cell_normals_or_null);
 
+  /* Per-point normals of a triangle mesh, computed on the device: the normalised sum of the
+   * unit normals of the faces at each point (zero for a point without faces).  Replaces the
+   * filter's own vtkPolyDataNormals with splitting off
+   * (ICP/vtkPolyDataCorrespondenceFilter.cxx:356-359, run at :457-464), whose output the
+   * symmetric metric takes as source normals; pass the result to icpx_set_source.
+   * normals_out: 3 * nv floats.  The context only supplies the device and the stream. */
+  int icpx_point_normals(icpx_ctx* ctx, const float* xyz, int64_t nv, const int32_t* tri,
+    int64_t nt, float* normals_out);
+
   /* Source points (float, as vtkICP requires: ICP/vtkICP.cxx:145-150) and
    * optional per-point normals (needed by the symmetric metric; the reference
    * takes them from vtkPolyDataNormals, ICP/vtkPolyDataCorrespondenceFilter.cxx:457-471). */

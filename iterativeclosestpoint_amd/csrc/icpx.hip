@@ -1024,6 +1024,87 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   return ICPX_OK;
 }
 
+extern "C" int icpx_point_normals(icpx_ctx* c, const float* xyz, int64_t nv, const int32_t* tri,
+  int64_t nt, float* normals_out)
+{
+  if (!c || !xyz || !tri || !normals_out)
+    return fail(ICPX_E_INVALID, "icpx_point_normals: null argument");
+  if (nv <= 0 || nt <= 0)
+    return fail(ICPX_E_INVALID, "icpx_point_normals: empty mesh (%lld points, %lld triangles)",
+      (long long)nv, (long long)nt);
+  if (nv >= (1ll << 31) || nt >= (1ll << 28) * 4)
+    return fail(ICPX_E_INVALID, "icpx_point_normals: mesh too large");
+  for (int64_t i = 0; i < 3 * nt; i++)
+    if (tri[i] < 0 || tri[i] >= nv)
+      return fail(ICPX_E_INVALID, "icpx_point_normals: triangle %lld refers to point %d of %lld",
+        (long long)(i / 3), tri[i], (long long)nv);
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  float *d_xyz = nullptr, *d_pn = nullptr, *fn32 = nullptr;
+  int32_t *d_tri = nullptr, *vcell = nullptr;
+  double* fn64 = nullptr;
+  uint32_t *voff = nullptr, *cursor = nullptr, *sscr = nullptr;
+  auto drop = [&]() {
+    dev_free(&d_xyz);
+    dev_free(&d_pn);
+    dev_free(&fn32);
+    dev_free(&d_tri);
+    dev_free(&vcell);
+    dev_free(&fn64);
+    dev_free(&voff);
+    dev_free(&cursor);
+    dev_free(&sscr);
+  };
+  int rc = dev_alloc(&d_xyz, 3 * nv);
+  if (!rc)
+    rc = dev_alloc(&d_pn, 3 * nv);
+  if (!rc)
+    rc = dev_alloc(&fn32, 3 * nt);
+  if (!rc)
+    rc = dev_alloc(&d_tri, 3 * nt);
+  if (!rc)
+    rc = dev_alloc(&vcell, 3 * nt);
+  if (!rc)
+    rc = dev_alloc(&fn64, 3 * nt);
+  if (!rc)
+    rc = dev_alloc(&voff, nv + 1);
+  if (!rc)
+    rc = dev_alloc(&cursor, nv + 1);
+  if (!rc)
+    rc = dev_alloc(&sscr, scan_scratch_words(nv + 1));
+  if (rc)
+  {
+    drop();
+    return rc;
+  }
+  hipError_t e = hipMemcpyAsync(d_xyz, xyz, sizeof(float) * 3 * nv, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(d_tri, tri, sizeof(int32_t) * 3 * nt, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(voff, 0, sizeof(uint32_t) * (nv + 1), st);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (nv + 1), st);
+  if (e == hipSuccess)
+  {
+    // the same face normals and links as the target's tables are made from
+    k_face_normals<<<nblk(nt, 256), 256, 0, st>>>(d_xyz, d_tri, nullptr, nt, fn64, fn32);
+    k_valence<<<nblk(3 * nt, 256), 256, 0, st>>>(d_tri, 3 * nt, voff);
+    exclusive_scan(voff, voff, nv + 1, sscr, st);
+    k_fill_links<<<nblk(3 * nt, 256), 256, 0, st>>>(d_tri, 3 * nt, voff, cursor, vcell);
+    k_sort_links<<<nblk(nv, 256), 256, 0, st>>>(voff, nv, vcell);
+    k_point_normals<<<nblk(nv, 256), 256, 0, st>>>(voff, vcell, fn64, nv, d_pn);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(normals_out, d_pn, sizeof(float) * 3 * nv, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  drop();
+  if (e != hipSuccess)
+    return fail(ICPX_E_HIP, "icpx_point_normals failed: %s", hipGetErrorString(e));
+  return ICPX_OK;
+}
+
 // K3: the box hierarchy for one fan-out, built on first use.
 static int ensure_tree(icpx_ctx* c, int G)
 {

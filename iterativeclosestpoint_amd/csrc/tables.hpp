@@ -86,6 +86,31 @@ __global__ void k_sort_links(
   }
 }
 
+// Point normals of a source mesh as the filter's own vtkPolyDataNormals makes them with
+// splitting off (ICP/vtkPolyDataCorrespondenceFilter.cxx:356-359,457-464): the normalised sum
+// of the unit normals of the faces at the point, one term per corner, in link order (fixed,
+// so the result repeats run to run); a point without faces, or whose terms cancel, gets zero.
+__global__ void k_point_normals(const uint32_t* __restrict__ voff,
+  const int32_t* __restrict__ vcell, const double* __restrict__ fn64, int64_t nv,
+  float* __restrict__ pn32)
+{
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv)
+    return;
+  d3 s = mk(0.0, 0.0, 0.0);
+  for (uint32_t q = voff[v]; q < voff[v + 1]; q++)
+  {
+    const int64_t c = vcell[q];
+    s.x += fn64[3 * c];
+    s.y += fn64[3 * c + 1];
+    s.z += fn64[3 * c + 2];
+  }
+  normalize(s);
+  pn32[3 * v] = (float)s.x;
+  pn32[3 * v + 1] = (float)s.y;
+  pn32[3 * v + 2] = (float)s.z;
+}
+
 // Angle-weighted pseudo-normal of every point (:475-516).
 __device__ __forceinline__ d3 vertex_normal64(const float* __restrict__ xyz,
   const int32_t* __restrict__ tri, const uint32_t* __restrict__ voff,

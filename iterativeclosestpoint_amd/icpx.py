@@ -27,6 +27,7 @@ SYMBOLS = (
     "icpx_reset_hints", "icpx_set_timing", "icpx_get_timing", "icpx_set_exhaustive",
     "icpx_set_leaf_size", "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local",
     "icpx_run_begin", "icpx_run_enqueue", "icpx_run_update", "icpx_run_end", "icpx_set_refill",
+    "icpx_point_normals",
 )
 
 
@@ -66,6 +67,7 @@ def load():
     lib.icpx_synchronize.argtypes = [vp]
     lib.icpx_set_target.argtypes = [vp, vp, i64, vp, i64, vp]
     lib.icpx_set_source.argtypes = [vp, vp, i64, vp]
+    lib.icpx_point_normals.argtypes = [vp, vp, i64, vp, i64, vp]
     lib.icpx_set_shard.argtypes = [vp, ci, ci]
     lib.icpx_get_origin.argtypes = [vp, vp]
     lib.icpx_accumulate.argtypes = [vp, ci, vp, i64, dbl, dbl, ci, vp, vp]
@@ -244,6 +246,16 @@ class Context:
             if len(cn) != len(tri):
                 raise ValueError("cell_normals must have one row per triangle")
         _chk(load().icpx_set_target(self._h, _p(xyz), len(xyz), _p(tri), len(tri), _p(cn)))
+
+    def point_normals(self, xyz, tri):
+        """Per-point normals of a triangle mesh (normalised sum of the unit normals of the faces
+        at each point), computed on the device: what the filter's own vtkPolyDataNormals
+        yields with splitting off (ICP/vtkPolyDataCorrespondenceFilter.cxx:356-359,457-464)."""
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        tri = np.ascontiguousarray(tri, np.int32).reshape(-1, 3)
+        out = np.zeros_like(xyz)
+        _chk(load().icpx_point_normals(self._h, _p(xyz), len(xyz), _p(tri), len(tri), _p(out)))
+        return out
 
     def set_source(self, xyz, normals=None):
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)

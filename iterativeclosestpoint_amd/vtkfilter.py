@@ -21,7 +21,7 @@ import sys
 import numpy as np
 
 from . import icpx
-from .vtkicp import point_normals_like_vtkPolyDataNormals, vtkPolyData
+from .vtkicp import vtkPolyData
 
 VTK_INT_MAX = 2147483647
 
@@ -183,11 +183,9 @@ class vtkPolyDataCorrespondenceFilter:
         if target.GetNumberOfCells() == 0:
             return self._fail("No polygons to evaluate function!")
         sn = None
-        if self.IncludeOriginNormals:
-            if source.GetNumberOfCells() > 0:
-                sn = point_normals_like_vtkPolyDataNormals(source.GetPoints(), source.GetPolys())
-            else:
-                sn = source.GetPointNormals()
+        own_normals = self.IncludeOriginNormals and source.GetNumberOfCells() > 0
+        if self.IncludeOriginNormals and not own_normals:
+            sn = source.GetPointNormals()
             if sn is None or len(sn) != source.GetNumberOfPoints():
                 return self._fail("Number of vertex normals does not match the number of points")
 
@@ -200,6 +198,9 @@ class vtkPolyDataCorrespondenceFilter:
             self._target_key = tkey
         skey = (id(source), id(source.GetPoints()), self.IncludeOriginNormals)
         if skey != self._source_key:
+            if own_normals:
+                # the filter's own vtkPolyDataNormals (.cxx:356-359,457-464), on the device
+                sn = self._ctx.point_normals(source.GetPoints(), source.GetPolys())
             self._ctx.set_source(source.GetPoints(), sn)
             self._source_key = skey
 

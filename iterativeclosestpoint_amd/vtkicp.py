@@ -73,22 +73,6 @@ class vtkPolyData:
         self._cell_normals = None if other._cell_normals is None else other._cell_normals.copy()
 
 
-def point_normals_like_vtkPolyDataNormals(points, polys):
-    """Point normals with splitting off: normalised sum of the unit normals of the incident
-    faces (what the filter's own vtkPolyDataNormals yields,
-    ICP/vtkPolyDataCorrespondenceFilter.cxx:356-359,457-464)."""
-    p = np.asarray(points, np.float64)
-    a, b, c = p[polys[:, 0]], p[polys[:, 1]], p[polys[:, 2]]
-    fn = np.cross(b - a, c - a)
-    ln = np.linalg.norm(fn, axis=1, keepdims=True)
-    fn = fn / np.where(ln > 0, ln, 1.0)
-    vn = np.zeros_like(p)
-    for k in range(3):
-        np.add.at(vn, polys[:, k], fn)
-    ln = np.linalg.norm(vn, axis=1, keepdims=True)
-    return (vn / np.where(ln > 0, ln, 1.0)).astype(np.float32)
-
-
 def icp_loop(accumulate, allreduce, origin, metric, max_iterations, check_mean_distance,
              max_mean_distance):
     """The iterate loop of vtkICP::InternalUpdate (ICP/vtkICP.cxx:189-246).
@@ -278,7 +262,8 @@ class vtkICP:
     def _source_normals(self):
         src = self.Source
         if src.GetNumberOfCells() > 0:
-            return point_normals_like_vtkPolyDataNormals(src.GetPoints(), src.GetPolys())
+            # the filter's own vtkPolyDataNormals (ICP/vtkPolyDataCorrespondenceFilter.cxx:457-464)
+            return self._ctx.point_normals(src.GetPoints(), src.GetPolys())
         return src.GetPointNormals()
 
     def _upload(self):
@@ -289,9 +274,9 @@ class vtkICP:
         if tkey != self._target_key:
             self._ctx.set_target(tgt.GetPoints(), tgt.GetPolys(), tgt.GetCellNormals())
             self._target_key = tkey
-        sn = self._source_normals() if self.Metric == vtkICP.MetricPlaneToPlane else None
         skey = (id(src), id(src.GetPoints()), self.Metric == vtkICP.MetricPlaneToPlane)
         if skey != self._source_key:
+            sn = self._source_normals() if self.Metric == vtkICP.MetricPlaneToPlane else None
             self._ctx.set_source(src.GetPoints(), sn)
             self._source_key = skey
 

@@ -180,6 +180,23 @@ class Mesh:
         return T.reshape(4, 4), it.value, md.value, st, ln.value
 
 
+def point_normals(points, polys):
+    """Point normals as the filter's own vtkPolyDataNormals yields them with splitting off
+    (ICP/vtkPolyDataCorrespondenceFilter.cxx:356-359, run at :457-464): the normalised sum of
+    the unit normals of the incident faces, one term per corner; zero where nothing adds up."""
+    p = np.asarray(points, np.float32).astype(np.float64)
+    polys = np.asarray(polys).reshape(-1, 3)
+    a, b, c = p[polys[:, 0]], p[polys[:, 1]], p[polys[:, 2]]
+    fn = np.cross(b - a, c - a)
+    ln = np.linalg.norm(fn, axis=1, keepdims=True)
+    fn = fn / np.where(ln > 0, ln, 1.0)
+    vn = np.zeros_like(p)
+    for k in range(3):
+        np.add.at(vn, polys[:, k], fn)
+    ln = np.linalg.norm(vn, axis=1, keepdims=True)
+    return (vn / np.where(ln > 0, ln, 1.0)).astype(np.float32)
+
+
 def solve(metric, s, t, ns=None, nt=None, precision=64):
     """One solver step on fp32 rows; returns (M 4x4, status)."""
     s = np.ascontiguousarray(s, np.float32).reshape(-1, 3)

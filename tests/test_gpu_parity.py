@@ -356,8 +356,7 @@ def test_filter_surface(icpx, synth, oracle):
     f.SetMinNormalDot(0.9999)
     f.SetMaximumNumberOfLandmarks(10 ** 9)
     f.Update()
-    from iterativeclosestpoint_amd.vtkicp import point_normals_like_vtkPolyDataNormals
-    sn = point_normals_like_vtkPolyDataNormals(moved, tri)
+    sn = oracle.point_normals(moved, tri)
     ref = mesh_t.correspond(moved, T=Tinv, step=1, max_dist=0.05, src_normals=sn, min_dot=0.9999,
                             grid=True)
     assert 0 < len(ref["cell"]) < len(moved)                   # the normals are not rotated (Q7)
@@ -891,6 +890,29 @@ def test_tree_and_far_certificates_are_sound(icpx, synth, oracle):
         assert np.all(cert[pos][near] <= (d[:, 1] - d[:, 0])[near] + 1e-12)
         assert np.all(d[:, 0][near | (cert[pos] == 0)] >= 0)
         assert np.all(-cert[pos][far] <= d[:, 0][far] - cap + 1e-12)
+
+
+def test_point_normals_on_device(icpx, synth, oracle):
+    """icpx_point_normals against the numpy restatement of the filter's vtkPolyDataNormals
+    (normalised sum of incident unit face normals): a closed surface, plus a point no triangle
+    uses (zero normal), a degenerate triangle (adds nothing) and two faces that cancel."""
+    xyz, tri = synth.bumpy_torus(120, 60)
+    extra = np.array([[5, 5, 5], [6, 5, 5], [6, 6, 5], [7, 7, 7]], np.float32)
+    n0 = len(xyz)
+    xyz2 = np.concatenate([xyz, extra])
+    tri2 = np.concatenate([tri, np.array([[n0, n0 + 1, n0 + 2], [n0, n0 + 2, n0 + 1],  # cancel
+                                          [n0 + 1, n0 + 1, n0 + 2]], np.int32)])     # degenerate
+    ctx = icpx.Context(0)
+    got = ctx.point_normals(xyz2, tri2)
+    want = oracle.point_normals(xyz2, tri2)
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.abs(got - want).max() <= 1e-6   # (sums in a different order: a unit in the last place)
+    assert np.all(got[n0:] == 0)
+    ln = np.linalg.norm(got[:n0].astype(np.float64), axis=1)
+    assert np.abs(ln - 1).max() < 1e-6
+    assert np.array_equal(got, ctx.point_normals(xyz2, tri2))  # repeats bit for bit
+    with pytest.raises(icpx.IcpxError):
+        ctx.point_normals(xyz2, np.array([[0, 1, len(xyz2)]], np.int32))
 
 
 def _sharded_rank(rank, world, port, metric, out):
