@@ -4,6 +4,7 @@ counted and must be zero on these seeds), distances and closest points bit-exact
 normals within 1e-6 (the device's acos may differ from libm's by an ulp before the
 float rounding), sums within 1e-11 relative, 4x4 transforms within 1e-6 relative."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -913,6 +914,38 @@ def test_point_normals_on_device(icpx, synth, oracle):
     assert np.array_equal(got, ctx.point_normals(xyz2, tri2))  # repeats bit for bit
     with pytest.raises(icpx.IcpxError):
         ctx.point_normals(xyz2, np.array([[0, 1, len(xyz2)]], np.int32))
+
+
+def test_registration_demo_from_a_file(icpx, synth, tmp_path, capsys):
+    """The headless registration demo end to end: a PLY file written here, read by the reader
+    factory, perturbed as the reference's demo does and registered back with every metric."""
+    import importlib.util
+    xyz, tri = synth.bumpy_torus(64, 32)
+    path = tmp_path / "surface.ply"
+    with open(path, "wb") as fh:
+        fh.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\n"
+                  "property float y\nproperty float z\nelement face %d\n"
+                  "property list uchar int vertex_indices\nend_header\n" % (len(xyz), len(tri))).encode())
+        fh.write(xyz.astype("<f4").tobytes())
+        rec = np.zeros(len(tri), np.dtype([("n", "u1"), ("v", "<i4", 3)]))
+        rec["n"], rec["v"] = 3, tri
+        fh.write(rec.tobytes())
+    spec = importlib.util.spec_from_file_location(
+        "registration_demo", os.path.join(os.path.dirname(__file__), "..", "tools", "registration_demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    for metric, tol in (("point", 5e-3), ("plane", 1e-4), ("symmetric", 1e-4)):
+        argv = sys.argv
+        sys.argv = ["registration_demo.py", str(path), "--metric", metric, "--landmarks", "1000000",
+                    "--iterations", "60", "--max-mean-distance", "1e-7"]
+        try:
+            assert demo.main() == 0
+        finally:
+            sys.argv = argv
+        out = capsys.readouterr().out
+        assert "Number of iterations:" in out and "Mean distance:" in out
+        worst = float(out.strip().splitlines()[-1].split(":")[1])
+        assert worst < tol, (metric, out)
 
 
 def _sharded_rank(rank, world, port, metric, out):
