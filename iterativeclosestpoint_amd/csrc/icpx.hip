@@ -21,6 +21,7 @@
 #include <atomic>
 #include <cstring>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <new>
 #include <vector>
@@ -306,6 +307,10 @@ struct icpx_ctx
   };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
+  // the search kernels' pair rides on the first and the last kernel of the pass themselves
+  // (their own start and end times) instead of two markers in the queue, each of which
+  // holds the next kernel back by ~6 us
+  hipEvent_t ev_first = nullptr, ev_last = nullptr;
   double t_ms[2] = { 0.0, 0.0 };
   int64_t t_n[2] = { 0, 0 };
 };
@@ -347,9 +352,11 @@ struct ScopedTimer
   icpx_ctx* c;
   hipEvent_t a = nullptr, b = nullptr;
   int which;
-  ScopedTimer(icpx_ctx* ctx, int w)
+  bool attach; // the events ride on the pass's first and last kernel (launch_ev)
+  ScopedTimer(icpx_ctx* ctx, int w, bool att = false)
     : c(ctx)
     , which(w)
+    , attach(att)
   {
     if (!c->timing || (c->timing == 2 && which != 0))
       return;
@@ -360,18 +367,44 @@ struct ScopedTimer
     }
     a = take_event(c);
     b = take_event(c);
-    if (a)
+    if (attach && a && b)
+    {
+      c->ev_first = a; // (taken by the launches: launch_ev)
+      c->ev_last = b;
+    }
+    else if (a)
       (void)hipEventRecord(a, c->stream);
   }
   ~ScopedTimer()
   {
     if (!a && !b)
       return;
-    if (b)
+    if (attach && a && b)
+    {
+      // (a pass that ended before its launches leaves a pair that was never recorded;
+      // resolve_timing skips it)
+      c->ev_first = nullptr;
+      c->ev_last = nullptr;
+    }
+    else if (b)
       (void)hipEventRecord(b, c->stream);
     c->pending.push_back({ a, b, which });
   }
 };
+
+// A launch that may carry the pass's timing events: the first kernel of the search takes
+// the start event, the last one (last == true) the stop event.
+template <typename... KArgs, typename... Args>
+static void launch_ev(icpx_ctx* c, bool last, void (*kernel)(KArgs...), unsigned grid,
+  unsigned block, hipStream_t st, Args... args)
+{
+  hipEvent_t e0 = c->ev_first, e1 = last ? c->ev_last : nullptr;
+  c->ev_first = nullptr;
+  if (e0 || e1)
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, e0, e1, 0, args...);
+  else
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, args...);
+}
 
 template <typename T>
 static int dev_alloc(T** p, int64_t count)
@@ -1321,26 +1354,26 @@ static int ensure_bin(icpx_ctx* c, int L)
 }
 
 template <int L>
-static void launch_search3(const Search3Args& a, unsigned grid, unsigned pgrid, unsigned wgrid,
-  int mode, const Search2Args* wide, hipStream_t st)
+static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, unsigned pgrid,
+  unsigned wgrid, int mode, const Search2Args* wide, hipStream_t st)
 {
   if (wide && pgrid && mode == 1)
-    k_fallback<L><<<pgrid, 256, 0, st>>>(a, *wide);
+    launch_ev(c, false, k_fallback<L>, pgrid, 256, st, a, *wide);
   else if (mode == 3 && a.cert)
-    k_search3w<L, true><<<wgrid, 64, 0, st>>>(a);
+    launch_ev(c, false, k_search3w<L, true>, wgrid, 64, st, a);
   else if (mode == 3)
-    k_search3w<L, false><<<wgrid, 64, 0, st>>>(a);
+    launch_ev(c, false, k_search3w<L, false>, wgrid, 64, st, a);
   else if (pgrid && mode == 2)
-    k_search3q<L><<<pgrid, 256, 0, st>>>(a);
+    launch_ev(c, false, k_search3q<L>, pgrid, 256, st, a);
   else if (pgrid)
-    k_search3p<L><<<pgrid, 256, 0, st>>>(a);
+    launch_ev(c, false, k_search3p<L>, pgrid, 256, st, a);
   else
-    k_search3<L, false><<<grid, 256, 0, st>>>(a);
+    launch_ev(c, false, k_search3<L, false>, grid, 256, st, a);
   unsigned rgrid = grid / 8 + 1;
   if (rgrid > 2048)
     rgrid = 2048;
   // (overflows are rare: a bounded number of blocks takes them in turns)
-  k_contested<L><<<rgrid + std::min(grid, 256u), 256, 0, st>>>(a, rgrid);
+  launch_ev(c, true, k_contested<L>, rgrid + std::min(grid, 256u), 256, st, a, rgrid);
 }
 
 // Neighbour lists of every leaf of the one-triangle-per-leaf tree for radius eps (see
@@ -1551,7 +1584,7 @@ static int run_search3(icpx_ctx* c)
   c->since_cold = c->hint_valid ? c->since_cold + 1 : 0;
   c->pass_certs = c->use_cert && (mode == 1 || (mode == 3 && c->since_cold >= 2));
   a.cert = c->pass_certs ? c->d_cert : nullptr;
-  ScopedTimer tm(c, 0);
+  ScopedTimer tm(c, 0, true);
   if (!c->counters_clean)
     HIPCHK(hipMemsetAsync(c->d_counters, 0, PASS_COUNTERS * sizeof(uint32_t), st));
   c->counters_clean = false;
@@ -1595,7 +1628,7 @@ static int run_search3(icpx_ctx* c)
       ca.rounds = (int)std::min<int64_t>(std::max<int64_t>(c->nq / (256 * 2048), 1), CERTIFY_ROUNDS);
       const unsigned cgrid = nblk(c->nq, 256 * ca.rounds);
       ca.segcap = (int64_t)((cgrid + CERTIFY_SEGS - 1) / CERTIFY_SEGS) * 256 * ca.rounds;
-      k_certify<<<cgrid, 256, 0, st>>>(ca);
+      launch_ev(c, false, k_certify, cgrid, 256, st, ca);
       la.work = c->d_work;
       la.work_count = c->d_counters + 16;
       la.segcap = ca.segcap;
@@ -1606,9 +1639,9 @@ static int run_search3(icpx_ctx* c)
         lgrid = cap;
     }
     if (la.work)
-      k_search_local<true><<<lgrid, 256, 0, st>>>(la);
+      launch_ev(c, false, k_search_local<true>, lgrid, 256, st, la);
     else
-      k_search_local<false><<<lgrid, 256, 0, st>>>(la);
+      launch_ev(c, false, k_search_local<false>, lgrid, 256, st, la);
     a.qlist = c->d_fallback; // the tree kernel serves what is left,
     a.use_hint = 1;          // starting from the triangles the shortcut reached
     c->local_passes++;
@@ -1650,11 +1683,11 @@ static int run_search3(icpx_ctx* c)
     widep = &wide;
   }
   if (L == 1)
-    launch_search3<1>(a, grid, pgrid, wgrid, mode, widep, st);
+    launch_search3<1>(c, a, grid, pgrid, wgrid, mode, widep, st);
   else if (L == 2)
-    launch_search3<2>(a, grid, pgrid, wgrid, mode, widep, st);
+    launch_search3<2>(c, a, grid, pgrid, wgrid, mode, widep, st);
   else
-    launch_search3<4>(a, grid, pgrid, wgrid, mode, widep, st);
+    launch_search3<4>(c, a, grid, pgrid, wgrid, mode, widep, st);
   LAUNCHCHK();
   c->hint_valid = true;
   return ICPX_OK;
