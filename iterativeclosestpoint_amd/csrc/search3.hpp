@@ -890,10 +890,7 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
 // stragglers of a converged pass) is served one WAVEFRONT per query instead, over the
 // 64-ary tree of search2.hpp (a few steps of 64 box tests each); a long list by the
 // pooled lanes.  Same results either way.
-#ifndef ICPX_FALLBACK_SMALL
-#define ICPX_FALLBACK_SMALL 16384u
-#endif
-constexpr uint32_t FALLBACK_SMALL = ICPX_FALLBACK_SMALL;
+constexpr uint32_t FALLBACK_SMALL = 16384;
 
 template <int L>
 __global__ __launch_bounds__(256) void k_fallback(Search3Args a, Search2Args w)
