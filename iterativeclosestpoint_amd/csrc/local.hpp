@@ -340,9 +340,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   // (a listed query with the top bit set passed the check and stands on a set certificate)
   bool local = false, certified = (entry >> 31) != 0u, certset = certified;
   float sec2 = 0.f; // lower bound of the squared distance of every triangle outside the ring
-                    // but ru, the nearest of those that were screened (ru2: its bound)
-  float ru2 = INFINITY;
-  int32_t ru = -1;
   // (the listed queries are the ones whose certificates failed)
   const bool cert_on = a.cert && !LISTED && a.use_hint && __builtin_amdgcn_readfirstlane(okv) != 0;
   // far certificates hold for the cap they were made for, or a smaller one
@@ -514,42 +511,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     d3 P0, P1, P2;
     load_tri(a.tverts, s, P0, P1, P2);
     const double d2 = tri_d2_screen(x, P0, P1, P2);
-    // (as note_screened, but the nearest triangle outside the ring keeps its name: ru)
+    sec2 = note_screened(sec2, d2, best, bound, tau, cnt);
     if (d2 < best)
-    {
-      const double r = sqrt(d2) + tau;
-      if (r * r < best && cnt > 0)
-      {
-        // the ring's members fall behind: they were at least the old minimum away
-        const float ob = __double2float_rd(best) * 0.999999f;
-        if (cnt == 1 && ob < ru2)
-        {
-          sec2 = fminf(sec2, ru2);
-          ru2 = ob;
-          ru = ring[0][tid];
-        }
-        else
-          sec2 = fminf(sec2, ob);
-      }
       set_best(d2);
-    }
     if (d2 <= bound)
     {
       if (cnt < RING3)
         ring[cnt][tid] = s;
       cnt++;
-    }
-    else
-    {
-      const float f = __double2float_rd(d2) * 0.999999f;
-      if (f < ru2)
-      {
-        sec2 = fminf(sec2, ru2);
-        ru2 = f;
-        ru = s;
-      }
-      else
-        sec2 = fminf(sec2, f);
     }
   };
   while (local && e < eend)
@@ -572,8 +541,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
       if (s < 0 || s == hs)
         continue;
       const float g2 = qbox_g2(wq[k], gx, gy, gz);
-      // (likewise a box that is next to nothing away, when certificates are kept)
-      if (g2 > boundg && (!a.cert || g2 * step2lo > 64.f * eabs * eabs))
+      if (g2 > boundg)
       {
         sec2 = fminf(sec2, g2 * step2lo); // ruled out by its box: at least that far
         continue;
@@ -581,9 +549,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
       const float ex = edge_excess(la.edges, s, xf, yf, zf, alw);
       if (a.tid[s] < 0)
         continue; // degenerate: never a closest cell
-      // (when certificates are kept, a triangle that is outside an edge by next to nothing
-      // is screened all the same: its excess would be a worthless bound of its distance)
-      if (ex > 0.f && ex * ex * 0.999999f > boundf && (!a.cert || ex > 8.f * eabs))
+      if (ex > 0.f && ex * ex * 0.999999f > boundf)
       {
         sec2 = fminf(sec2, ex * ex * 0.999999f); // outside an edge by more than the bound
         continue;
@@ -605,24 +571,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     if (local && cnt >= 1 && cnt <= RING3)
     {
       const float dw = __double2float_ru(sqrt(best));
-      const float base = dw * 1.000001f + 2.1f * (float)tau +
+      slack = __builtin_amdgcn_sqrtf(sec2) * 0.999999f - dw * 1.000001f - 2.1f * (float)tau -
         fminf(eabs, 0.2f * eabs * eabs / fmaxf(dw, 1e-30f)); // (see make_certificate)
-      slack = __builtin_amdgcn_sqrtf(fminf(sec2, ru2)) * 0.999999f - base;
-      if (!(slack > 0.f) && ru >= 0 && cnt < RING3)
-      {
-        // The runner-up is too close for the winner to stand alone (a query next to an edge:
-        // any move, or the screen's own rounding, could swap them), but everybody else is
-        // not: the runner-up joins the ring, and the two are weighed by exact evaluation in
-        // this and later passes, which names the same winner as long as nobody else comes
-        // near.  Without this such a query would be searched again in every pass.
-        const float s2 = __builtin_amdgcn_sqrtf(sec2) * 0.999999f - base;
-        if (s2 > 0.f)
-        {
-          ring[cnt][tid] = ru;
-          cnt++;
-          slack = s2;
-        }
-      }
     }
     a.cert[q] = cert_encode(slack, cnt >= 2);
   }
