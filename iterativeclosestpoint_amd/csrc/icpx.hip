@@ -117,13 +117,9 @@ __global__ void k_solve(RunState* s, const double* __restrict__ sums, int metric
 {
   if (threadIdx.x != 0 || blockIdx.x != 0)
     return;
-  if (!s->done)
-  {
-    const double origin[3] = { ox, oy, oz };
-    s->fallback = counters ? counters[7] : 0u; // snapshot of the pass's fallback count
-    solve_step(s, sums, metric, origin, check_mean, max_mean);
-  }
-  publish_record(s, rec, seq);
+  const double origin[3] = { ox, oy, oz };
+  solve_and_publish(s, sums, metric, origin, check_mean, max_mean, true, counters ? counters[7] : 0u,
+    rec, seq);
 }
 
 // The reduction and the solve in one launch, for a loop with nothing between them (one
@@ -153,13 +149,9 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
   if (threadIdx.x != 0)
     return;
   *ticket = 0u;
-  if (ran && !s->done)
-  {
-    const double origin[3] = { ox, oy, oz };
-    s->fallback = counters ? counters[7] : 0u; // snapshot of the pass's fallback count
-    solve_step(s, tot, metric, origin, check_mean, max_mean);
-  }
-  publish_record(s, rec, seq);
+  const double origin[3] = { ox, oy, oz };
+  solve_and_publish(s, tot, metric, origin, check_mean, max_mean, ran, counters ? counters[7] : 0u,
+    rec, seq);
 }
 
 // From this many queries on, a pass that finds certificates checks them in a kernel of its

@@ -33,54 +33,69 @@ struct RunRecord
   uint32_t pad_;
 };
 // One iteration's solve and transform update in a single GPU thread: the body of the
-// loop in vtkICP::InternalUpdate after the correspondence filter (ICP/vtkICP.cxx:218-245).
-__device__ inline void solve_step(RunState* s, const double* __restrict__ sums, int metric,
-  const double* origin, int check_mean, double max_mean)
+// loop in vtkICP::InternalUpdate after the correspondence filter (ICP/vtkICP.cxx:218-245),
+// and the iteration's record for the host, written straight to pinned host memory, where
+// the host finds it two iterations later by its serial number (no event, hence no marker
+// in the queue between iterations).  run: this pass ran and the registration is not over;
+// fallback_now: the pass's count of queries the shortcut left to the tree walk.
+// (Everything the step reads is requested at once and the record is written from
+// registers: one lane's chain of dependent reads is what this costs.)
+__device__ inline void solve_and_publish(RunState* s, const double* __restrict__ sums, int metric,
+  const double* origin, int check_mean, double max_mean, bool ran, uint32_t fallback_now,
+  RunRecord* rec, uint32_t seq)
 {
-  double M[16], n = 0.0, md = 0.0;
-  const int rc = icpx_core::solve_moments(metric, sums, origin, M, &n, &md);
-  s->mean = md;
-  s->n = n;
-  if (check_mean && n > 0.0 && md <= max_mean)
-  {
-    s->status = ICPX_RUN_CONVERGED;
-    s->done = 1;
-    return;
-  }
-  if (rc != ICPX_OK)
-  {
-    s->status = ICPX_RUN_TOO_FEW;
-    s->done = 1;
-    return;
-  }
-  s->iters = s->iters + 1;
-  double R[16];
-  for (int r = 0; r < 4; r++)
-    for (int k = 0; k < 4; k++)
-    {
-      double acc = 0.0;
-      for (int j = 0; j < 4; j++)
-        acc += M[4 * r + j] * s->T[4 * j + k];
-      R[4 * r + k] = acc;
-    }
+  double Tm[16];
+#pragma unroll
   for (int i = 0; i < 16; i++)
-    s->T[i] = R[i];
-}
-
-// The iteration's record for the host: written straight to pinned host memory, where the
-// host finds it two iterations later by its serial number (no event, hence no marker in
-// the queue between iterations).
-__device__ inline void publish_record(const RunState* s, RunRecord* rec, uint32_t seq)
-{
-  rec->mean = s->mean;
-  rec->n = s->n;
-  rec->iters = s->iters;
-  rec->status = s->status;
-  rec->done = s->done;
-  rec->fallback = s->fallback;
+    Tm[i] = s->T[i];
+  double mean = s->mean, n = s->n;
+  int32_t iters = s->iters, status = s->status, done = s->done;
+  uint32_t fallback = s->fallback;
+  if (ran && !done)
+  {
+    fallback = fallback_now;
+    s->fallback = fallback;
+    double M[16];
+    const int rc = icpx_core::solve_moments(metric, sums, origin, M, &n, &mean);
+    s->mean = mean;
+    s->n = n;
+    if (check_mean && n > 0.0 && mean <= max_mean)
+    {
+      status = ICPX_RUN_CONVERGED;
+      done = 1;
+    }
+    else if (rc != ICPX_OK)
+    {
+      status = ICPX_RUN_TOO_FEW;
+      done = 1;
+    }
+    else
+    {
+      iters++;
+      s->iters = iters;
+      for (int r = 0; r < 4; r++)
+        for (int k = 0; k < 4; k++)
+        {
+          double acc = 0.0;
+          for (int j = 0; j < 4; j++)
+            acc += M[4 * r + j] * Tm[4 * j + k];
+          s->T[4 * r + k] = acc;
+        }
+    }
+    if (done)
+    {
+      s->status = status;
+      s->done = 1;
+    }
+  }
+  rec->mean = mean;
+  rec->n = n;
+  rec->iters = iters;
+  rec->status = status;
+  rec->done = done;
+  rec->fallback = fallback;
   __threadfence_system();
   *reinterpret_cast<volatile uint32_t*>(&rec->seq) = seq;
-  __threadfence_system();
 }
 
 } // namespace icpx
