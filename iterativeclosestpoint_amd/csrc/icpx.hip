@@ -1349,7 +1349,23 @@ template <int L>
 static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, unsigned pgrid,
   unsigned wgrid, int mode, const Search2Args* wide, hipStream_t st)
 {
-  if (wide && pgrid && mode == 1)
+  if (pgrid && mode == 1 && a.qlist && a.cert && a.nq >= c->certify_min)
+  {
+    // The leftovers of a large cloud: the host does not know how many there are.  Most of
+    // the cloud (the first passes with the shortcut, when hardly any query holds a
+    // certificate yet) is served faster by the wavefront walk, a scattered few percent by
+    // the pooled lanes: both are enqueued, and the one whose side of nq/2 the list's length
+    // is on does the work (the other's blocks return after one read).
+    Search3Args lo = a, hi = a;
+    lo.list_hi = a.nq / 2;
+    hi.list_lo = a.nq / 2;
+    if (wide)
+      launch_ev(c, false, k_fallback<L>, pgrid, 256, st, lo, *wide);
+    else
+      launch_ev(c, false, k_search3p<L>, pgrid, 256, st, lo);
+    launch_ev(c, false, k_search3w<L, true>, wgrid, 64, st, hi);
+  }
+  else if (wide && pgrid && mode == 1)
     launch_ev(c, false, k_fallback<L>, pgrid, 256, st, a, *wide);
   else if (mode == 3 && a.cert)
     launch_ev(c, false, k_search3w<L, true>, wgrid, 64, st, a);
@@ -1549,6 +1565,8 @@ static int run_search3(icpx_ctx* c)
   a.ovf_list = c->d_ovf_list;
   a.ovf_best = c->d_ovf_best;
   a.qlist = nullptr;
+  a.list_lo = 0;
+  a.list_hi = INT64_MAX;
   a.cap2 = c->cap2;
   a.cert = nullptr; // (set below, once the pass's kernels are known)
   a.cert_T = c->d_state->cert_T;

@@ -161,6 +161,9 @@ struct Search3Args
 {
   const float* qpos;
   int64_t nq;
+  // a kernel given a list serves it only if its length is in [list_lo, list_hi): two
+  // kernels can be enqueued over one list and the one that suits its length does the work
+  int64_t list_lo, list_hi;
   XfRef T;
   const float* nodes;
   BinTree tree;
@@ -636,6 +639,8 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
   const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
   if ((int64_t)blockIdx.x * 256 >= total)
     return; // a short list is served by the first blocks; the rest must not queue at the pool
+  if (a.qlist && (total < a.list_lo || total >= a.list_hi))
+    return; // (left to the other kernel enqueued over this list)
 #ifdef ICPX_STATS
   unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0;
 #endif
@@ -896,8 +901,8 @@ template <int L>
 __global__ __launch_bounds__(256) void k_fallback(Search3Args a, Search2Args w)
 {
   const uint32_t total = a.counters[3];
-  if (total == 0u)
-    return; // (most converged passes: gone after one read)
+  if (total == 0u || (int64_t)total < a.list_lo || (int64_t)total >= a.list_hi)
+    return; // (most converged passes: gone after one read; or the other kernel's list)
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
@@ -991,6 +996,8 @@ __global__ __launch_bounds__(256) void k_search3q(Search3Args a)
   const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
   if ((int64_t)blockIdx.x * 256 >= total)
     return; // a short list is served by the first blocks; the rest must not queue at the pool
+  if (a.qlist && (total < a.list_lo || total >= a.list_hi))
+    return; // (left to the other kernel enqueued over this list)
 #ifdef ICPX_STATS
   unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0;
 #endif
@@ -1308,6 +1315,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
   const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
   if ((int64_t)blockIdx.x * 64 >= total)
     return; // a short list is served by the first blocks; the rest must not queue at the pool
+  if (a.qlist && (total < a.list_lo || total >= a.list_hi))
+    return; // (left to the other kernel enqueued over this list)
   // (read-only for the whole launch and addressed uniformly: eligible for the scalar path)
   // certificates are checked here only on a whole pass (a list holds what failed the check)
   bool cert_on = false, far_on = false;

@@ -766,7 +766,10 @@ def test_certificates_change_nothing(icpx, synth, oracle):
         assert np.array_equal(sums[0], sums[1]) and np.array_equal(sums[0], sums[2])
         assert np.array_equal(sums[0], sums[3])
         kept.append(float((ctxs[0].debug_certificates(len(src)) > 0).mean()))
-        assert np.array_equal(ctxs[0].debug_certificates(len(src)), ctxs[3].debug_certificates(len(src)))
+        # (with the certificates checked by their own kernel a long list of leftovers goes to
+        # another tree kernel, whose certificates are as sound but not the same numbers)
+        kept3 = float((ctxs[3].debug_certificates(len(src)) > 0).mean())
+        assert abs(kept3 - kept[-1]) < 0.05
     assert ctxs[0].debug_stats()["local_passes"] >= 20
     assert min(kept[2:8]) > 0.9 and kept[-1] > 0.9  # most queries hold a certificate
 
@@ -877,20 +880,19 @@ def test_tree_and_far_certificates_are_sound(icpx, synth, oracle):
         ctx.accumulate(1, T, step=1, max_dist=cap)
         plain.accumulate(1, T, step=1, max_dist=cap)
         listed.accumulate(1, T, step=1, max_dist=cap)
-    cert = ctx.debug_certificates(len(src))
-    assert np.array_equal(cert, listed.debug_certificates(len(src)))
-    order = ctx.debug_query_order(len(src))
-    assert (cert > 0).mean() > 0.3 and (cert < 0).mean() > 0.1
     P = xyz[tri].astype(np.float64)
     x = src.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
-    for k0 in range(0, 40_000, 8000):
-        pos = np.arange(k0, k0 + 400)
-        d = np.sort(_point_triangle_dist(x[order[pos]], P), axis=1)
-        near, far = cert[pos] > 0, cert[pos] < 0
-        near &= (cert[pos].view(np.uint32) & 1) == 0  # (set certificates: tested elsewhere)
-        assert np.all(cert[pos][near] <= (d[:, 1] - d[:, 0])[near] + 1e-12)
-        assert np.all(d[:, 0][near | (cert[pos] == 0)] >= 0)
-        assert np.all(-cert[pos][far] <= d[:, 0][far] - cap + 1e-12)
+    for c_ in (ctx, listed):  # (the listed path's leftovers may have gone to another tree kernel)
+        cert = c_.debug_certificates(len(src))
+        order = c_.debug_query_order(len(src))
+        assert (cert > 0).mean() > 0.3 and (cert < 0).mean() > 0.1
+        for k0 in range(0, 40_000, 8000):
+            pos = np.arange(k0, k0 + 400)
+            d = np.sort(_point_triangle_dist(x[order[pos]], P), axis=1)
+            near, far = cert[pos] > 0, cert[pos] < 0
+            near &= (cert[pos].view(np.uint32) & 1) == 0  # (set certificates: tested elsewhere)
+            assert np.all(cert[pos][near] <= (d[:, 1] - d[:, 0])[near] + 1e-12)
+            assert np.all(-cert[pos][far] <= d[:, 0][far] - cap + 1e-12)
 
 
 def test_point_normals_on_device(icpx, synth, oracle):
