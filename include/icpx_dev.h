@@ -1,0 +1,112 @@
+/*
+ * icpx_dev.h — development and measurement entry points of libicpx.
+ *
+ * Nothing here replaces a reference interface: these calls select between kernel variants
+ * that return the same results, read internal arrays back for tests, and time kernels for
+ * the benchmark.  A binding of the reference's classes needs include/icpx.h only.
+ */
+#ifndef ICPX_DEV_H
+#define ICPX_DEV_H
+
+#include "icpx.h"
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+  /* Wall-clock seconds the last icpx_set_target spent building the BVH and
+   * tables on the device (for reporting). */
+  double icpx_last_build_seconds(icpx_ctx* ctx);
+
+  /* Search-kernel variant: lanes that cooperate on one query.  1 = one lane per
+   * query over a binary box tree (large clouds); 4, 8, 16, 32 or 64 = that many
+   * lanes per query over a tree of the same fan-out (64 = one wavefront per
+   * query, for a few hundred landmarks); 0 = choose from the number of queries.
+   * Trees are built on first use.  Results do not depend on the choice. */
+  int icpx_set_group_width(icpx_ctx* ctx, int lanes);
+
+  /* Triangles per leaf of the lane-per-query kernel's tree: 1, 2 or 4 (default). */
+  int icpx_set_leaf_size(icpx_ctx* ctx, int triangles);
+
+  /* Hinted shortcut of the lane-per-query path: 1 (default) = once the mean residual is a
+   * fraction of the target's edge length, queries close to their previous winner test only
+   * the triangles near it (per-triangle neighbour lists, built once per target) instead of
+   * walking the tree; the rest still walk it.  A query settled that way with a single
+   * contender also keeps a certificate: a lower bound of how much farther every other
+   * triangle is, less the tie tolerance; while twice its accumulated move stays below that,
+   * later passes keep its winner without searching (a search would return it again).  A
+   * query with several contenders at the same distance (on an edge or a vertex) keeps the
+   * set of them the same way: while the certificate lasts only the exact evaluation of
+   * those few is repeated.
+   * 2 = the shortcut without certificates.  0 = always walk the tree.  3 = as 1, with the
+   * certificates checked by a light kernel of their own and the shortcut run over the
+   * queries that failed (what 1 does by itself for clouds of four million points and more,
+   * where the extra launch pays).  Same results. */
+  int icpx_set_local(icpx_ctx* ctx, int enable);
+
+  /* Tree kernel of the lane-per-query path.  4 (default) = by regime: a whole pass over a
+   * cloud about as dense as the mesh runs one walk per wavefront (the 64 neighbouring
+   * queries of a wavefront share the walk; node and triangle records are read once per
+   * wavefront), what the shortcut leaves over and sparse clouds run one pooled lane per
+   * query.  3 = always one walk per wavefront; 1 = always pooled lanes (a resident grid
+   * whose lanes draw queries from a pool as they finish).  Same results. */
+  int icpx_set_persistent(icpx_ctx* ctx, int mode);
+
+  /* Pooled kernels: how many of a wavefront's 64 lanes must be idle before it takes new
+   * queries off the pool.  0 (default) = by regime (56 on a cold pass, 40 on a hinted one).
+   * Same results. */
+  int icpx_set_refill(icpx_ctx* ctx, int lanes);
+
+  /* Search kernel selection.  0 (default): the production kernel, which screens
+   * triangles with a short fp64 routine and evaluates only near-ties (within
+   * 1e-9 x the largest coordinate of the minimum) with the reference's exact
+   * arithmetic.  1: the exhaustive kernel, which evaluates every visited
+   * triangle exactly.  Both return the same winners; the second exists as a
+   * cross-check. */
+  int icpx_set_exhaustive(icpx_ctx* ctx, int enable);
+
+  /* Diagnostic: copy an internal array to the host.  what = 0: winners of the last search
+   * pass (Morton positions of triangles, int32 per query of this shard); 1: Morton
+   * position -> cell id (int32 per triangle, -1-id for a degenerate one); 2: {ties,
+   * overflows, pool position, shortcut fallbacks} of the last lane-per-query pass (4 x
+   * uint32); 3: screened minima of the queries whose contenders overflowed (double per
+   * query); 4: {shortcut passes, tree-only passes, neighbour-list builds, list radius x
+   * 1e9, list entries, passes whose certificates were checked by the light kernel, passes
+   * that enqueued both tree kernels over the leftovers} (7 x int64); 5: the shortcut's
+   * certificates (float per query of
+   * this shard: how far the query may still move before its winner is looked at again,
+   * 0 = none, negative = how far before something may come within the distance threshold;
+   * a positive value whose last mantissa bit is set stands for a set of contenders rather
+   * than a single winner); 6: the library's query order (int32 per query: position -> kept
+   * index within the shard; arrays 0, 5 and 7 are in this order); 7: the contender sets
+   * (8 x int32 per query, Morton positions, -1 ends a shorter set; meaningful for queries
+   * whose certificate stands for a set). */
+  int icpx_debug_dump(icpx_ctx* ctx, int what, void* out, int64_t count);
+
+  /* Forget the winners of the previous search pass.  A pass normally starts each
+   * query from the triangle that won last time (only as an upper bound: results
+   * do not depend on it); after this call the next pass starts cold, as the
+   * first iteration of a new vtkICP::Update() does. */
+  int icpx_reset_hints(icpx_ctx* ctx);
+
+  /* Measurement aid: record HIP events on the context's stream around every launch of the
+   * search kernels and of the finalize/reduction kernel.  icpx_get_timing synchronises and
+   * returns the accumulated kernel milliseconds and launch counts since timing was
+   * enabled.  enable = 2 times the search kernels only (every event is a marker in the
+   * queue that costs a few microseconds between launches). */
+  int icpx_set_timing(icpx_ctx* ctx, int enable);
+  int icpx_get_timing(icpx_ctx* ctx, double* search_ms, int64_t* search_launches,
+    double* finalize_ms, int64_t* finalize_launches);
+
+  /* The same measurement pass by pass: the search kernels' milliseconds of the passes
+   * timed since icpx_set_timing, oldest first (at most `cap` of them are copied);
+   * *n_out = how many there are.  kind_out (optional, int32 per pass): 0 = a whole pass of
+   * the tree kernel (a cold pass when hinted_out is 0), 1 = the hinted shortcut first. */
+  int icpx_get_pass_timings(icpx_ctx* ctx, double* ms_out, int32_t* kind_out,
+    int32_t* hinted_out, int64_t cap, int64_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICPX_DEV_H */

@@ -4,6 +4,7 @@
 // per-point arithmetic runs on the GPU and the only host arithmetic is the O(1)
 // solve in solve.cpp.
 #include "../../include/icpx.h"
+#include "../../include/icpx_dev.h"
 #include "bvh.hpp"
 #include "prims.hpp"
 #include "query.hpp"
@@ -189,7 +190,7 @@ struct icpx_ctx
   Heap heaps[5];  // group kernel's heap-ordered trees
   Bin bins[3];    // lane-per-query kernel's binary trees (1, 2, 4 triangles per leaf)
   int leaf_size = 4;
-  int persistent = 4; // 0 static lanes, 1 pooled, 2 pooled + queued screens, 3 one walk per wavefront, 4 by regime
+  int persistent = 4; // tree kernel: 1 pooled lanes, 3 one walk per wavefront, 4 by regime
   int wave_blocks = 19; // blocks per CU of the one-walk-per-wavefront kernel
   int num_cus = 256;
   // hinted shortcut: per-leaf neighbour lists for one radius, and the residual statistics
@@ -233,9 +234,12 @@ struct icpx_ctx
   uint32_t rec_seq = 0;                      // serial number of the last solve enqueued
   uint32_t slot_seq[4] = { 0, 0, 0, 0 };     // ... and of the solve that writes each record slot
   bool run_active = false, run_done_known = false;
+  double record_wait_limit = 120.0; // seconds the host waits for one iteration's record
   int64_t run_it = 0, run_step = 1;
   icpx_params run_p;
   int64_t local_passes = 0, tree_passes = 0, nbr_builds = 0, nbr_total = 0;
+  int64_t certify_passes = 0; // passes whose certificates were checked by k_certify
+  int64_t split_passes = 0;   // passes that enqueued both tree kernels over the leftovers
   // lane-per-query kernel's tie bookkeeping, sized for q3_cap queries
   int64_t q3_cap = 0;
   int32_t* d_cand = nullptr;
@@ -296,7 +300,15 @@ struct icpx_ctx
   {
     hipEvent_t a, b;
     int which; // 0 search, 1 finalize
+    int kind;  // search: 0 a whole pass of the tree kernel, 1 the hinted shortcut first
+    int hinted; // search: the pass started from last pass's winners
   };
+  struct PassTime
+  {
+    double ms;
+    int kind, hinted;
+  };
+  std::vector<PassTime> pass_times; // the search kernels' time pass by pass (icpx_get_pass_timings)
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
   // the search kernels' pair rides on the first and the last kernel of the pass themselves
@@ -330,6 +342,8 @@ static void resolve_timing(icpx_ctx* c)
     {
       c->t_ms[p.which] += ms;
       c->t_n[p.which]++;
+      if (p.which == 0 && c->pass_times.size() < (1u << 20))
+        c->pass_times.push_back({ (double)ms, p.kind, p.hinted });
     }
     if (p.a)
       c->free_events.push_back(p.a);
@@ -344,6 +358,7 @@ struct ScopedTimer
   icpx_ctx* c;
   hipEvent_t a = nullptr, b = nullptr;
   int which;
+  int kind = 0, hinted = 0;
   bool attach; // the events ride on the pass's first and last kernel (launch_ev)
   ScopedTimer(icpx_ctx* ctx, int w, bool att = false)
     : c(ctx)
@@ -380,7 +395,7 @@ struct ScopedTimer
     }
     else if (b)
       (void)hipEventRecord(b, c->stream);
-    c->pending.push_back({ a, b, which });
+    c->pending.push_back({ a, b, which, kind, hinted });
   }
 };
 
@@ -670,6 +685,29 @@ extern "C" int icpx_set_timing(icpx_ctx* c, int enable)
   c->timing = enable < 0 ? 0 : enable > 2 ? 2 : enable;
   c->t_ms[0] = c->t_ms[1] = 0.0;
   c->t_n[0] = c->t_n[1] = 0;
+  c->pass_times.clear();
+  return ICPX_OK;
+}
+
+extern "C" int icpx_get_pass_timings(icpx_ctx* c, double* ms_out, int32_t* kind_out,
+  int32_t* hinted_out, int64_t cap, int64_t* n_out)
+{
+  if (!c || !n_out)
+    return fail(ICPX_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  resolve_timing(c);
+  const int64_t n = (int64_t)c->pass_times.size();
+  *n_out = n;
+  for (int64_t i = 0; i < std::min(n, cap); i++)
+  {
+    if (ms_out)
+      ms_out[i] = c->pass_times[(size_t)i].ms;
+    if (kind_out)
+      kind_out[i] = c->pass_times[(size_t)i].kind;
+    if (hinted_out)
+      hinted_out[i] = c->pass_times[(size_t)i].hinted;
+  }
   return ICPX_OK;
 }
 
@@ -720,9 +758,9 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
   }
   else if (what == 4)
   {
-    int64_t v[5] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
-      c->nbr_total };
-    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 5));
+    int64_t v[7] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
+      c->nbr_total, c->certify_passes, c->split_passes };
+    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 7));
     return ICPX_OK;
   }
   else if (what == 3 && c->d_ovf_best)
@@ -798,12 +836,14 @@ extern "C" int icpx_set_refill(icpx_ctx* c, int lanes)
   return ICPX_OK;
 }
 
-extern "C" int icpx_set_persistent(icpx_ctx* c, int enable)
+extern "C" int icpx_set_persistent(icpx_ctx* c, int mode)
 {
-
   if (!c)
     return fail(ICPX_E_INVALID, "null context");
-  c->persistent = enable < 0 ? 0 : enable > 4 ? 4 : enable;
+  if (mode != 1 && mode != 3 && mode != 4)
+    return fail(ICPX_E_INVALID, "tree kernel must be 1 (pooled lanes), 3 (one walk per "
+                                "wavefront) or 4 (by regime); got %d", mode);
+  c->persistent = mode;
   return ICPX_OK;
 }
 
@@ -865,6 +905,7 @@ extern "C" void icpx_default_params(icpx_params* p)
   p->check_mean_distance = 0;
   p->max_mean_distance = 0.01;
   p->min_normal_dot = 0.0;
+  p->rotate_source_normals = 0;
 }
 
 // ------------------------------------------------------------------ target ----
@@ -969,12 +1010,17 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   k_tri_bounds<<<nblk(nt + TPRE_PAD, 256), 256, 0, st>>>(
     c->d_tverts, c->d_tid, nt, nt + TPRE_PAD, c->d_tpre);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess && dev_alloc(&c->d_tcodes, nt) == ICPX_OK)
+  if (e == hipSuccess)
+    rc = dev_alloc(&c->d_tcodes, nt);
+  if (e == hipSuccess && !rc)
     e = hipMemcpyAsync(
       c->d_tcodes, which ? k1 : k0, sizeof(uint64_t) * nt, hipMemcpyDeviceToDevice, st);
+  const hipError_t es = hipStreamSynchronize(st); // (the sort's buffers are in use until here)
   if (e == hipSuccess)
-    e = hipStreamSynchronize(st);
+    e = es;
   drop_sort();
+  if (rc)
+    return rc;
   if (e != hipSuccess)
     return fail(ICPX_E_HIP, "target ordering failed: %s", hipGetErrorString(e));
 
@@ -1356,6 +1402,7 @@ static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, uns
     // certificate yet) is served faster by the wavefront walk, a scattered few percent by
     // the pooled lanes: both are enqueued, and the one whose side of nq/2 the list's length
     // is on does the work (the other's blocks return after one read).
+    c->split_passes++;
     Search3Args lo = a, hi = a;
     lo.list_hi = a.nq / 2;
     hi.list_lo = a.nq / 2;
@@ -1371,12 +1418,8 @@ static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, uns
     launch_ev(c, false, k_search3w<L, true>, wgrid, 64, st, a);
   else if (mode == 3)
     launch_ev(c, false, k_search3w<L, false>, wgrid, 64, st, a);
-  else if (pgrid && mode == 2)
-    launch_ev(c, false, k_search3q<L>, pgrid, 256, st, a);
-  else if (pgrid)
-    launch_ev(c, false, k_search3p<L>, pgrid, 256, st, a);
   else
-    launch_ev(c, false, k_search3<L, false>, grid, 256, st, a);
+    launch_ev(c, false, k_search3p<L>, pgrid, 256, st, a);
   unsigned rgrid = grid / 8 + 1;
   if (rgrid > 2048)
     rgrid = 2048;
@@ -1595,6 +1638,8 @@ static int run_search3(icpx_ctx* c)
   c->pass_certs = c->use_cert && (mode == 1 || (mode == 3 && c->since_cold >= 2));
   a.cert = c->pass_certs ? c->d_cert : nullptr;
   ScopedTimer tm(c, 0, true);
+  tm.kind = use_local ? 1 : 0;
+  tm.hinted = c->hint_valid ? 1 : 0;
   if (!c->counters_clean)
     HIPCHK(hipMemsetAsync(c->d_counters, 0, PASS_COUNTERS * sizeof(uint32_t), st));
   c->counters_clean = false;
@@ -1639,6 +1684,7 @@ static int run_search3(icpx_ctx* c)
       const unsigned cgrid = nblk(c->nq, 256 * ca.rounds);
       ca.segcap = (int64_t)((cgrid + CERTIFY_SEGS - 1) / CERTIFY_SEGS) * 256 * ca.rounds;
       launch_ev(c, false, k_certify, cgrid, 256, st, ca);
+      c->certify_passes++;
       la.work = c->d_work;
       la.work_count = c->d_counters + 16;
       la.segcap = ca.segcap;
@@ -1659,13 +1705,9 @@ static int run_search3(icpx_ctx* c)
   else
     c->tree_passes++;
   // persistent lanes: as many wavefronts as stay resident, each drawing queries from a pool
-  unsigned pgrid = 0;
-  if (c->persistent || use_local)
-  {
-    pgrid = (unsigned)c->num_cus * 5u;
-    if (pgrid > grid)
-      pgrid = grid;
-  }
+  unsigned pgrid = (unsigned)c->num_cus * 5u;
+  if (pgrid > grid)
+    pgrid = grid;
   // one walk per wavefront: single-wavefront blocks, a resident set of them
   unsigned wgrid = nblk(c->nq, 64);
   if (wgrid > (unsigned)c->num_cus * (unsigned)c->wave_blocks)
@@ -1835,6 +1877,7 @@ static void fill_final(icpx_ctx* c, FinalArgs& f, double max_dist,
   f.max_dist = max_dist;
   f.min_dot = min_dot;
   f.use_sn = use_sn;
+  f.rotate_sn = use_sn == 2 ? 1 : 0;
   f.partials = c->d_partials;
 }
 
@@ -1844,6 +1887,8 @@ static int check_call(icpx_ctx* c, const double* T, int metric, int use_sn)
     return fail(ICPX_E_INVALID, "null argument");
   if (metric < 0 || metric > 2)
     return fail(ICPX_E_INVALID, "unknown metric %d", metric);
+  if (use_sn < 0 || use_sn > 2)
+    return fail(ICPX_E_INVALID, "use_source_normals must be 0, 1 or 2 (got %d)", use_sn);
   if ((metric == ICPX_METRIC_PLANE_TO_PLANE || use_sn) && !c->d_srcn)
     return fail(ICPX_E_INVALID, "Plane to plane metric requires source normals");
   for (int i = 0; i < 16; i++)
@@ -2239,6 +2284,7 @@ static int run_catch_up(icpx_ctx* c)
   // last); while waiting, look now and then whether the stream has drained without it
   const uint32_t want = c->slot_seq[slot];
   volatile const uint32_t* seen = &c->h_rec[slot].seq;
+  const auto t0 = std::chrono::steady_clock::now();
   for (uint64_t spins = 0; *seen != want; spins++)
   {
     if ((spins & 0xfffff) == 0xfffff)
@@ -2248,6 +2294,12 @@ static int run_catch_up(icpx_ctx* c)
         return fail(ICPX_E_HIP, "iteration record %u never arrived", want);
       if (e != hipSuccess && e != hipErrorNotReady)
         return fail(ICPX_E_HIP, "stream failed: %s", hipGetErrorString(e));
+      // a kernel that never finishes must not hold the host for ever
+      const double waited =
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (waited > c->record_wait_limit)
+        return fail(ICPX_E_HIP, "iteration record %u did not arrive within %.0f s", want,
+          c->record_wait_limit);
     }
     __builtin_ia32_pause();
   }
@@ -2273,8 +2325,8 @@ static int run_enqueue_impl(icpx_ctx* c, double* sums_device, int* done_out, boo
     return ICPX_OK;
   const icpx_params& p = c->run_p;
   return enqueue_pass(c, p.metric, c->run_step, p.max_distance, p.min_normal_dot,
-    p.metric == ICPX_METRIC_PLANE_TO_PLANE ? 1 : 0, sums_device ? sums_device : c->d_sums, false,
-    fuse_solve);
+    p.metric == ICPX_METRIC_PLANE_TO_PLANE ? (p.rotate_source_normals ? 2 : 1) : 0,
+    sums_device ? sums_device : c->d_sums, false, fuse_solve);
 }
 
 extern "C" int icpx_run_enqueue(icpx_ctx* c, double* sums_device, int* done_out)
@@ -2359,7 +2411,8 @@ extern "C" int icpx_run(icpx_ctx* c, const icpx_params* p, double T_out[16], int
     T[i] = (i % 5 == 0) ? 1.0 : 0.0;
   c->hint_valid = false; // every Update() starts cold
   const int64_t step = landmark_step(c, p);
-  const int use_sn = p->metric == ICPX_METRIC_PLANE_TO_PLANE ? 1 : 0;
+  const int use_sn =
+    p->metric == ICPX_METRIC_PLANE_TO_PLANE ? (p->rotate_source_normals ? 2 : 1) : 0;
   int iters = 0, status = ICPX_RUN_MAX_ITERATIONS;
   double mean = 0.0;
   double sums[ICPX_NSUMS];

@@ -267,6 +267,7 @@ struct FinalArgs
   const int32_t* hint;
   double max_dist, min_dot;
   int use_sn;
+  int rotate_sn; // source normals are rotated by T's 3x3 first (the corrected mode)
   // rows, indexed by kept index (ROWS only)
   float* o_origin;
   float* o_onormal;
@@ -424,6 +425,15 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))
         sf[0] = a.qsn[3 * p];
         sf[1] = a.qsn[3 * p + 1];
         sf[2] = a.qsn[3 * p + 2];
+        if (a.rotate_sn)
+        {
+          // the normal of the moved point: T's 3x3 applied in fp64, rounded to float as the
+          // stored normals are (the reference leaves source normals unrotated)
+          const double sx = sf[0], sy = sf[1], sz = sf[2];
+          sf[0] = (float)(T.m[0] * sx + T.m[1] * sy + T.m[2] * sz);
+          sf[1] = (float)(T.m[4] * sx + T.m[5] * sy + T.m[6] * sz);
+          sf[2] = (float)(T.m[8] * sx + T.m[9] * sy + T.m[10] * sz);
+        }
         if (a.use_sn)
         {
           double dn = (double)nf[0] * (double)sf[0] + (double)nf[1] * (double)sf[1] +

@@ -15,8 +15,8 @@
 // of the minimum).  A query whose minimum is not contested is finished by this
 // kernel; contested ones (2..8 contenders) are listed and settled by
 // k_contested (resolve_ties_body), eight lanes per query, one contender per lane; the rare query
-// with more contenders than the ring holds is re-run by k_search3 in its
-// EXACT mode, which knows the final bound and evaluates every contender
+// with more contenders than the ring holds is re-run by search3_body in its
+// EXACT mode (k_contested's later blocks), which knows the final bound and evaluates every contender
 // exactly as it meets it.
 //
 // Replaces vtkCellLocator::FindClosestPoint as called from
@@ -169,7 +169,7 @@ struct Search3Args
   BinTree tree;
   const float* tverts;
   const int32_t* tid;
-  const float4* tpre; // per-triangle bounds records (k_tri_bounds), used by k_search3q
+  const float4* tpre; // per-triangle bounds records (k_tri_bounds), used by k_search3w
   int64_t nt;
   int32_t* hint;
   int use_hint;
@@ -585,12 +585,6 @@ __device__ __forceinline__ void search3_body(const Search3Args& a, unsigned bloc
   }
 }
 
-template <int L, bool EXACT>
-__global__ __launch_bounds__(256) void k_search3(Search3Args a)
-{
-  search3_body<L, EXACT>(a, blockIdx.x);
-}
-
 // The same search with lanes that outlive their queries.  A fixed grid of wavefronts
 // draws queries from a shared counter: whenever most of a wavefront's lanes (REFILL3 of
 // 64; taking queries is itself a costly step, so it is done for many lanes at once) have
@@ -920,21 +914,6 @@ __global__ __launch_bounds__(256) void k_fallback(Search3Args a, Search2Args w)
   }
 }
 
-// The pooled search with cheap bounds on both sides.  At a leaf every triangle yields, from
-// its eight-float record (tri_bounds), a lower bound of its distance to the query (plane
-// distance and in-plane distance to the circumscribing circle) and an upper bound (the
-// distance to its centroid).  The smallest upper bound seen tightens the pruning of boxes
-// and triangles just as an fp64 screen would; a triangle whose lower bound is within it
-// is only queued (per lane, in LDS).  The queue is screened in fp64 when the walk is over,
-// by then against the final bound, so a displaced query that meets 160 triangles screens
-// a handful, and it does so together with the other lanes that finished: the screen runs at
-// high lane utilisation instead of once per "some lane's triangle passed".  Same results
-// as k_search3p: bounds only ever remove triangles that cannot be contenders.
-constexpr int PEND3 = 8;
-#ifndef LEAFGO3Q
-#define LEAFGO3Q 16
-#endif
-
 // lower and upper fp32 bounds of the squared distance from the query to a triangle, from
 // its record {unit normal, plane allowance} {centroid, radius}
 // (RAW: the hardware's square root, within one unit in the last place, which the factors
@@ -957,313 +936,6 @@ __device__ __forceinline__ void tri_bounds_rec(float nx, float ny, float nz, flo
   // the stored centroid is within a rounding of a point of the triangle
   const float vhi = vlen * 1.000001f + 2.f * eabs;
   ub = vhi * vhi * 1.000001f;
-}
-__device__ __forceinline__ void tri_bounds(const float4* __restrict__ pre, int64_t s, float xf,
-  float yf, float zf, float eabs, float& lb, float& ub)
-{
-  const float4 a = pre[2 * s], b = pre[2 * s + 1];
-  tri_bounds_rec(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, xf, yf, zf, eabs, lb, ub);
-}
-
-template <int L>
-__global__ __launch_bounds__(256) void k_search3q(Search3Args a)
-{
-  Xf T;
-  if (!load_xf(a.T, T))
-    return; // the registration this pass belongs to has already stopped
-  __shared__ int32_t ring[RING3][256];
-  __shared__ int32_t pend_s[PEND3][256];
-  __shared__ float pend_lb[PEND3][256];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int d = a.tree.depth;
-
-  int64_t q = -1;
-  d3 x = mk(0.0, 0.0, 0.0);
-  float xf = 0.f, yf = 0.f, zf = 0.f, eabs = 0.f, tauf = 0.f;
-  double tau = 0.0, best = DBL_MAX, bound = DBL_MAX;
-  // boundf: from fp64 screens; ubf: smallest cheap upper bound; prunef: what triangles are
-  // tested against (the smaller of the two, the second widened by the tie tolerance);
-  // bboxf: the same for raw box distances
-  float boundf = FLT_MAX, ubf = FLT_MAX, prunef = FLT_MAX, bboxf = INFINITY;
-  int cnt = 0, npend = 0;
-  int32_t hs_used = -1;
-  uint32_t n = 1, trail = 0;
-  float lbleaf = 0.f;
-  // have: the lane holds a query; walked: its walk is over (queued triangles may remain)
-  bool have = false, walked = false, need_bt = false, atleaf = false;
-  bool dry = false; // the pool has run out (same for every lane of the wavefront)
-  const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
-  if ((int64_t)blockIdx.x * 256 >= total)
-    return; // a short list is served by the first blocks; the rest must not queue at the pool
-  if (a.qlist && (total < a.list_lo || total >= a.list_hi))
-    return; // (left to the other kernel enqueued over this list)
-#ifdef ICPX_STATS
-  unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0;
-#endif
-
-  auto retighten = [&]() {
-    const float r = __builtin_sqrtf(ubf) * 1.000001f + tauf;
-    prunef = fminf(boundf, r * r * 1.000001f);
-    bboxf = box_bound(prunef, eabs);
-  };
-  auto set_best = [&](double nb) {
-    const double r = sqrt(nb) + tau;
-    const double nbound = r * r;
-    if (nbound < best)
-      cnt = 0; // every older contender was above the old minimum
-    best = nb;
-    bound = nbound;
-    boundf = fminf(fmaxf(__double2float_ru(nbound), FLT_MIN), FLT_MAX);
-    retighten();
-  };
-  auto screen_one = [&]() { // the newest queued triangle, if it is still in the race
-    npend--;
-    const int32_t s = pend_s[npend][tid];
-    if (pend_lb[npend][tid] <= prunef)
-    {
-      STAT(3, 1);
-      d3 P0, P1, P2;
-      load_tri(a.tverts, s, P0, P1, P2);
-      const double d2 = tri_d2_screen(x, P0, P1, P2);
-      if (d2 < best)
-        set_best(d2);
-      if (d2 <= bound)
-      {
-        if (cnt < RING3)
-          ring[cnt][tid] = s;
-        cnt++;
-      }
-    }
-  };
-
-  while (true)
-  {
-    const bool idle = !have || walked;
-    const unsigned long long mi = __ballot(idle);
-    if (__popcll(mi) >= a.refill || __ballot(have && !walked) == 0ull)
-    {
-      // the lanes whose walks are over screen what they queued, together
-      while (__ballot(have && walked && npend > 0) != 0ull)
-        if (have && walked && npend > 0)
-          screen_one();
-      // results of the finished queries
-      const bool fin = have && walked;
-      const bool tie = fin && cnt >= 2 && cnt <= RING3;
-      const bool ovf = fin && cnt > RING3;
-      if (fin && !tie && !ovf)
-        a.hint[q] = (cnt == 1) ? ring[0][tid] : -1;
-      const unsigned long long mt = __ballot(tie);
-      if (mt)
-      {
-        const int leader = __ffsll((long long)mt) - 1;
-        uint32_t base = 0;
-        if (lane == leader)
-          base = atomicAdd(&a.counters[0], (uint32_t)__popcll(mt));
-        base = __shfl(base, leader, 64);
-        if (tie)
-        {
-          for (int i = 0; i < RING3; i++)
-            if (i <= cnt)
-              a.cand[q * RING3 + i] = i < cnt ? ring[i][tid] : -1;
-          a.tie_list[base + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
-        }
-      }
-      const unsigned long long mo = __ballot(ovf);
-      if (mo)
-      {
-        const int leader = __ffsll((long long)mo) - 1;
-        uint32_t base = 0;
-        if (lane == leader)
-          base = atomicAdd(&a.counters[1], (uint32_t)__popcll(mo));
-        base = __shfl(base, leader, 64);
-        if (ovf)
-        {
-          a.ovf_best[q] = best;
-          a.ovf_list[base + __popcll(mo & lt)] = (uint32_t)q;
-        }
-      }
-      have = have && !fin;
-
-      // next queries off the pool
-      if (!dry)
-      {
-        const bool want = !have;
-        const unsigned long long mw = __ballot(want);
-        const int leader = __ffsll((long long)mw) - 1;
-        uint32_t base = 0;
-        if (lane == leader)
-          base = atomicAdd(&a.counters[2], (uint32_t)__popcll(mw));
-        base = __shfl(base, leader, 64);
-        const int64_t nq_ = (int64_t)base + __popcll(mw & lt);
-        if (want && nq_ < total)
-        {
-          q = a.qlist ? (int64_t)a.qlist[nq_] : nq_;
-          have = true;
-          walked = false;
-          need_bt = false;
-          atleaf = false;
-          n = 1;
-          trail = 0;
-          cnt = 0;
-          npend = 0;
-          hs_used = -1;
-          best = DBL_MAX;
-          bound = DBL_MAX;
-          boundf = FLT_MAX;
-          ubf = FLT_MAX;
-          prunef = FLT_MAX;
-          bboxf = INFINITY;
-          x = xform(T, a.qpos + 3 * q);
-          xf = (float)x.x;
-          yf = (float)x.y;
-          zf = (float)x.z;
-          const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
-          eabs = smax * 2.3841858e-07f * 1.0000002f;
-          tau = 1e-9 * (double)smax;
-          tauf = 1.0000001e-9f * smax;
-          if (a.cap2 < 1e300)
-            set_best(a.cap2);
-          int32_t hs = a.use_hint ? a.hint[q] : -1;
-          if (hs < 0 && a.tcodes)
-          {
-            // cold start: the triangle that follows the query along the Morton curve
-            const uint64_t code = morton63(xf, yf, zf, a.box.lo, a.box.inv);
-            int64_t lo = 0, hi = a.nt;
-            while (lo < hi)
-            {
-              const int64_t mid = (lo + hi) >> 1;
-              if (a.tcodes[mid] < code)
-                lo = mid + 1;
-              else
-                hi = mid;
-            }
-            hs = (int32_t)min(lo, a.nt - 1);
-          }
-          if (hs >= 0 && a.tid[hs] >= 0)
-          {
-            d3 P0, P1, P2;
-            load_tri(a.tverts, hs, P0, P1, P2);
-            const double ds = tri_d2_screen(x, P0, P1, P2);
-            if (ds < best)
-            {
-              set_best(ds);
-              ring[0][tid] = hs;
-              cnt = 1;
-              hs_used = hs;
-            }
-          }
-        }
-        dry = __ballot(want && nq_ >= total) != 0ull;
-      }
-      STAT(5, lane == 0 ? 1 : 0);
-      if (__ballot(have) == 0ull)
-        break;
-    }
-    STAT(4, lane == 0 ? 1 : 0);
-
-    // (1) one step of the walk for every lane that is between leaves (see k_search3)
-    if (have && !walked && !atleaf)
-    {
-      if (need_bt)
-      {
-        if (trail == 0)
-          walked = true;
-        else
-        {
-          const int k = 31 - __clz(trail);
-          trail ^= 1u << k;
-          const int lvl = 31 - __clz(n);
-          n = (n >> (lvl - k - 1)) ^ 1u;
-          need_bt = false;
-          if (k == d - 1)
-          {
-            if (lbleaf > bboxf)
-              need_bt = true;
-            else
-              atleaf = true;
-          }
-        }
-      }
-      if (!walked && !need_bt && !atleaf)
-      {
-        STAT(0, 1);
-        const float4* p = reinterpret_cast<const float4*>(a.nodes + (int64_t)n * NODE_FLOATS);
-        const float4 u = p[0], v = p[1], w = p[2];
-        const float lb0 = box_d2(u.x, u.y, u.z, u.w, v.x, v.y, xf, yf, zf);
-        const float lb1 = box_d2(v.z, v.w, w.x, w.y, w.z, w.w, xf, yf, zf);
-        const bool ok0 = lb0 <= bboxf, ok1 = lb1 <= bboxf;
-        if (ok0 || ok1)
-        {
-          const uint32_t near = (ok1 && (!ok0 || lb1 < lb0)) ? 1u : 0u;
-          const int lvl = 31 - __clz(n);
-          if (ok0 && ok1)
-          {
-            trail |= 1u << lvl;
-            lbleaf = (lvl == d - 1) ? (near ? lb0 : lb1) : lbleaf;
-          }
-          n = 2u * n + near;
-          atleaf = (lvl == d - 1);
-        }
-        else
-        {
-          STAT(2, 1);
-          need_bt = true;
-        }
-      }
-    }
-
-    // (2) leaves: both cheap bounds on each triangle, once enough lanes stand on a leaf (or
-    // nobody can step)
-    const bool onleaf = have && !walked && atleaf;
-    const int nleaf = __popcll(__ballot(onleaf));
-    const bool anywalk = __ballot(have && !walked && !atleaf) != 0ull;
-    if (onleaf && (nleaf >= LEAFGO3Q || !anywalk))
-    {
-      STAT(1, 1);
-      // (a lane whose queue could overflow screens it first, on its own: rare)
-      while (npend > PEND3 - L)
-        screen_one();
-      const int64_t s0 = (int64_t)(n - (1u << d)) * L;
-      float lbs[L];
-      float ubmin = FLT_MAX;
-#pragma unroll
-      for (int t = 0; t < L; t++)
-      {
-        const int64_t s = s0 + t;
-        lbs[t] = FLT_MAX;
-        if (s < a.nt && a.tid[s] >= 0)
-        {
-          float ub;
-          tri_bounds(a.tpre, s, xf, yf, zf, eabs, lbs[t], ub);
-          ubmin = fminf(ubmin, ub);
-        }
-      }
-      if (ubmin < ubf)
-      {
-        ubf = ubmin;
-        retighten();
-      }
-#pragma unroll
-      for (int t = 0; t < L; t++)
-        if (lbs[t] <= prunef && (int32_t)(s0 + t) != hs_used)
-        {
-          pend_s[npend][tid] = (int32_t)(s0 + t);
-          pend_lb[npend][tid] = lbs[t];
-          npend++;
-        }
-      need_bt = true;
-      atleaf = false;
-    }
-  }
-#ifdef ICPX_STATS
-  atomicAdd(&g_stats[0], st_0);
-  atomicAdd(&g_stats[1], st_1);
-  atomicAdd(&g_stats[2], st_2);
-  atomicAdd(&g_stats[3], st_3);
-  atomicAdd(&g_stats[4], st_4);
-  atomicAdd(&g_stats[5], st_5);
-#endif
 }
 
 // The search with one walk per wavefront.  Queries are in Morton order, so the 64 of a

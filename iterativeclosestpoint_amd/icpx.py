@@ -19,15 +19,20 @@ RUN_MAX_ITERATIONS, RUN_CONVERGED, RUN_TOO_FEW = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ICPX_LIB") or os.path.join(_HERE, "libicpx.so")  # (ICPX_LIB: development builds)
 
+# entry points declared in include/icpx.h (the boundary a binding of the reference's classes uses)
 SYMBOLS = (
     "icpx_last_error", "icpx_device_count", "icpx_create", "icpx_destroy", "icpx_set_stream",
     "icpx_synchronize", "icpx_set_target", "icpx_set_source", "icpx_set_shard", "icpx_get_origin",
     "icpx_accumulate", "icpx_correspond", "icpx_correspond_f64", "icpx_solve", "icpx_default_params",
-    "icpx_set_allreduce", "icpx_run", "icpx_last_build_seconds", "icpx_set_group_width",
-    "icpx_reset_hints", "icpx_set_timing", "icpx_get_timing", "icpx_set_exhaustive",
-    "icpx_set_leaf_size", "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local",
-    "icpx_run_begin", "icpx_run_enqueue", "icpx_run_update", "icpx_run_end", "icpx_set_refill",
+    "icpx_set_allreduce", "icpx_run",
+    "icpx_run_begin", "icpx_run_enqueue", "icpx_run_update", "icpx_run_end",
     "icpx_point_normals",
+)
+# ... and in include/icpx_dev.h (kernel variants, diagnostics, timing)
+DEV_SYMBOLS = (
+    "icpx_last_build_seconds", "icpx_set_group_width", "icpx_reset_hints", "icpx_set_timing",
+    "icpx_get_timing", "icpx_get_pass_timings", "icpx_set_exhaustive", "icpx_set_leaf_size",
+    "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local", "icpx_set_refill",
 )
 
 
@@ -40,7 +45,8 @@ class IcpxError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("metric", C.c_int), ("max_iterations", C.c_int), ("max_landmarks", C.c_int64),
                 ("max_distance", C.c_double), ("check_mean_distance", C.c_int),
-                ("max_mean_distance", C.c_double), ("min_normal_dot", C.c_double)]
+                ("max_mean_distance", C.c_double), ("min_normal_dot", C.c_double),
+                ("rotate_source_normals", C.c_int)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
@@ -97,6 +103,7 @@ def load():
     lib.icpx_set_timing.argtypes = [vp, ci]
     lib.icpx_get_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl),
                                     C.POINTER(i64)]
+    lib.icpx_get_pass_timings.argtypes = [vp, vp, vp, vp, i64, C.POINTER(i64)]
     _lib = lib
     return lib
 
@@ -172,10 +179,11 @@ class Context:
 
     def debug_stats(self):
         """{shortcut passes, tree-only passes, neighbour-list builds, list radius}."""
-        v = np.zeros(5, np.int64)
-        _chk(load().icpx_debug_dump(self._h, 4, _p(v), 5))
+        v = np.zeros(7, np.int64)
+        _chk(load().icpx_debug_dump(self._h, 4, _p(v), 7))
         return dict(local_passes=int(v[0]), tree_passes=int(v[1]), nbr_builds=int(v[2]),
-                    nbr_eps=float(v[3]) * 1e-9, nbr_total=int(v[4]))
+                    nbr_eps=float(v[3]) * 1e-9, nbr_total=int(v[4]), certify_passes=int(v[5]),
+                    split_passes=int(v[6]))
 
     def debug_counters(self):
         """Counters of the last lane-per-query pass: {ties, overflows, pool position, fallbacks}."""
@@ -208,8 +216,9 @@ class Context:
         _chk(load().icpx_debug_dump(self._h, 7, _p(v), int(n) * 8))
         return v
 
-    def set_persistent(self, enable=True):
-        _chk(load().icpx_set_persistent(self._h, int(enable)))
+    def set_persistent(self, mode):
+        """Tree kernel: 1 pooled lanes, 3 one walk per wavefront, 4 by regime (default)."""
+        _chk(load().icpx_set_persistent(self._h, int(mode)))
 
     def set_refill(self, lanes):
         _chk(load().icpx_set_refill(self._h, int(lanes)))
@@ -233,6 +242,18 @@ class Context:
         na, nb = C.c_int64(0), C.c_int64(0)
         _chk(load().icpx_get_timing(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
         return a.value, na.value, b.value, nb.value
+
+    def get_pass_timings(self):
+        """Search-kernel milliseconds of every pass timed since set_timing, oldest first:
+        (ms float64[n], kind int32[n]: 1 = the hinted shortcut first, hinted int32[n])."""
+        n = C.c_int64(0)
+        _chk(load().icpx_get_pass_timings(self._h, None, None, None, 0, C.byref(n)))
+        ms = np.zeros(n.value, np.float64)
+        kind = np.zeros(n.value, np.int32)
+        hinted = np.zeros(n.value, np.int32)
+        _chk(load().icpx_get_pass_timings(self._h, _p(ms), _p(kind), _p(hinted), n.value,
+                                          C.byref(n)))
+        return ms, kind, hinted
 
     def set_group_width(self, lanes):
         _chk(load().icpx_set_group_width(self._h, int(lanes)))
@@ -283,18 +304,19 @@ class Context:
     def accumulate(self, metric, T, step=1, max_dist=10.0, min_dot=0.0, use_source_normals=None,
                    device_ptr=None):
         """Fused search + partial sums.  Returns the sums (numpy) unless device_ptr is given,
-        in which case they are left at that device address, stream-ordered."""
+        in which case they are left at that device address, stream-ordered.
+        use_source_normals: False/0, True/1 (as given), 2 (rotated by T: the corrected mode)."""
         T = np.ascontiguousarray(T, np.float64).reshape(16)
         if use_source_normals is None:
             use_source_normals = metric == METRIC_PLANE_TO_PLANE
         if device_ptr:
             _chk(load().icpx_accumulate(self._h, int(metric), _p(T), int(step), float(max_dist),
-                                        float(min_dot), int(bool(use_source_normals)), None,
+                                        float(min_dot), int(use_source_normals), None,
                                         C.c_void_p(device_ptr)))
             return None
         sums = np.zeros(NSUMS)
         _chk(load().icpx_accumulate(self._h, int(metric), _p(T), int(step), float(max_dist),
-                                    float(min_dot), int(bool(use_source_normals)), _p(sums), None))
+                                    float(min_dot), int(use_source_normals), _p(sums), None))
         return sums
 
     def correspond(self, T=None, step=1, max_dist=10.0, min_dot=0.0, use_source_normals=False):
@@ -310,7 +332,7 @@ class Context:
                    src_index=np.zeros(nk, np.int64))
         n = C.c_int64(0)
         _chk(load().icpx_correspond(
-            self._h, _p(T), step, float(max_dist), float(min_dot), int(bool(use_source_normals)),
+            self._h, _p(T), step, float(max_dist), float(min_dot), int(use_source_normals),
             _p(out["origin"]), _p(out["origin_normal"]), _p(out["closest"]), _p(out["normal"]),
             _p(out["cell"]), _p(out["dist"]), _p(out["src_index"]), C.byref(n)))
         return {k: v[:n.value] for k, v in out.items()}

@@ -77,7 +77,10 @@ class vtkPolyDataCorrespondenceFilter:
         return 2
 
     def Modified(self):
+        """Re-execute on the next Update() and read both inputs' current arrays again."""
         self._modified = True
+        self._target_key = None
+        self._source_key = None
 
     # --- parameters -------------------------------------------------------------------
     def SetTransform(self, t):
@@ -191,18 +194,18 @@ class vtkPolyDataCorrespondenceFilter:
 
         if self._ctx is None:
             self._ctx = icpx.Context(self._device)
-        tkey = (id(target), id(target.GetPoints()), id(target.GetPolys()),
-                id(target.GetCellNormals()))
-        if tkey != self._target_key:
+        # device copies are keyed on (object, its modification count); see vtkICP._upload
+        if self._target_key is None or self._target_key[0] is not target or \
+                self._target_key[1] != target.GetMTime():
             self._ctx.set_target(target.GetPoints(), target.GetPolys(), target.GetCellNormals())
-            self._target_key = tkey
-        skey = (id(source), id(source.GetPoints()), self.IncludeOriginNormals)
-        if skey != self._source_key:
+            self._target_key = (target, target.GetMTime())
+        if self._source_key is None or self._source_key[0] is not source or \
+                self._source_key[1:] != (source.GetMTime(), self.IncludeOriginNormals):
             if own_normals:
                 # the filter's own vtkPolyDataNormals (.cxx:356-359,457-464), on the device
                 sn = self._ctx.point_normals(source.GetPoints(), source.GetPolys())
             self._ctx.set_source(source.GetPoints(), sn)
-            self._source_key = skey
+            self._source_key = (source, source.GetMTime(), self.IncludeOriginNormals)
 
         n = source.GetNumberOfPoints()
         step = n // self.MaximumNumberOfLandmarks if n > self.MaximumNumberOfLandmarks else 1

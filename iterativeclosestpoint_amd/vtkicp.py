@@ -20,6 +20,7 @@ class vtkPolyData:
     """Points (float32 N x 3), triangles (int32 M x 3), optional normals."""
 
     def __init__(self, points=None, polys=None):
+        self._mtime = 0  # bumped by every setter and by Modified(), like vtkObject's MTime
         self._points = None
         self._polys = np.zeros((0, 3), np.int32)
         self._point_normals = None
@@ -30,7 +31,16 @@ class vtkPolyData:
         if polys is not None:
             self.SetPolys(polys)
 
+    def Modified(self):
+        """Mark the data as changed (call after editing an array in place): consumers
+        re-read it on their next Update(), as VTK's pipeline does on a newer MTime."""
+        self._mtime += 1
+
+    def GetMTime(self):
+        return self._mtime
+
     def SetPoints(self, pts):
+        self._mtime += 1
         pts = np.asarray(pts)
         self._point_dtype = pts.dtype  # vtkICP refuses anything but float (vtkICP.cxx:145-150)
         self._points = np.ascontiguousarray(pts).reshape(-1, 3)
@@ -42,6 +52,7 @@ class vtkPolyData:
         return 0 if self._points is None else len(self._points)
 
     def SetPolys(self, tri):
+        self._mtime += 1
         self._polys = np.ascontiguousarray(tri, np.int32).reshape(-1, 3)
 
     def GetPolys(self):
@@ -51,6 +62,7 @@ class vtkPolyData:
         return len(self._polys)
 
     def SetPointNormals(self, n):
+        self._mtime += 1
         # float, or double where the producer ran with double output precision
         dt = np.float64 if n is not None and np.asarray(n).dtype == np.float64 else np.float32
         self._point_normals = None if n is None else np.ascontiguousarray(n, dt).reshape(-1, 3)
@@ -59,6 +71,7 @@ class vtkPolyData:
         return self._point_normals
 
     def SetCellNormals(self, n):
+        self._mtime += 1
         self._cell_normals = None if n is None else np.ascontiguousarray(
             n, np.float32).reshape(-1, 3)
 
@@ -66,6 +79,7 @@ class vtkPolyData:
         return self._cell_normals
 
     def DeepCopy(self, other):
+        self._mtime += 1
         self._points = None if other._points is None else other._points.copy()
         self._point_dtype = other._point_dtype
         self._polys = other._polys.copy()
@@ -117,6 +131,7 @@ class vtkICP:
         self.MaximumNumberOfLandmarks = 200
         self.Metric = vtkICP.MetricPointToPlane
         self.MinNormalDot = 0.0
+        self.RotateSourceNormals = False  # opt-in corrected mode; the reference never rotates them
         self.Source = None
         self.Target = None
         self.Matrix = np.eye(4)
@@ -212,6 +227,16 @@ class vtkICP:
     def GetMeanDistance(self):
         return self.MeanDistance
 
+    def SetRotateSourceNormals(self, v):
+        """Not in the reference: with the plane-to-plane metric, rotate the source normals
+        with the running transform (the reference uses them as given in every iteration,
+        ICP/vtkPolyDataCorrespondenceFilter.cxx:284,299).  Off by default."""
+        self.RotateSourceNormals = bool(v)
+        self._modified = True
+
+    def GetRotateSourceNormals(self):
+        return self.RotateSourceNormals
+
     def Inverse(self):
         self.Source, self.Target = self.Target, self.Source
         self._modified = True
@@ -231,7 +256,12 @@ class vtkICP:
         self.Matrix = t.Matrix.copy()
 
     def Modified(self):
+        """An explicit Modified() also drops the device copies of both meshes: the next
+        Update() reads the current arrays again, as the reference does on every Update()
+        (arrays edited in place are picked up without a Modified() on the poly data)."""
         self._modified = True
+        self._target_key = None
+        self._source_key = None
 
     def PrintSelf(self, os=sys.stdout, indent=""):
         for k in ("Source", "Target"):
@@ -270,15 +300,18 @@ class vtkICP:
         if self._ctx is None:
             self._ctx = icpx.Context(self._device)
         tgt, src = self.Target, self.Source
-        tkey = (id(tgt), id(tgt.GetPoints()), id(tgt.GetPolys()), id(tgt.GetCellNormals()))
-        if tkey != self._target_key:
+        # Device copies are keyed on (object, its modification count): the object itself is
+        # kept in the key, so its identity cannot be reused by another one while it is there.
+        if self._target_key is None or self._target_key[0] is not tgt or \
+                self._target_key[1] != tgt.GetMTime():
             self._ctx.set_target(tgt.GetPoints(), tgt.GetPolys(), tgt.GetCellNormals())
-            self._target_key = tkey
-        skey = (id(src), id(src.GetPoints()), self.Metric == vtkICP.MetricPlaneToPlane)
-        if skey != self._source_key:
-            sn = self._source_normals() if self.Metric == vtkICP.MetricPlaneToPlane else None
+            self._target_key = (tgt, tgt.GetMTime())
+        sym = self.Metric == vtkICP.MetricPlaneToPlane
+        if self._source_key is None or self._source_key[0] is not src or \
+                self._source_key[1:] != (src.GetMTime(), sym):
+            sn = self._source_normals() if sym else None
             self._ctx.set_source(src.GetPoints(), sn)
-            self._source_key = skey
+            self._source_key = (src, src.GetMTime(), sym)
 
     def _params(self):
         p = icpx.default_params()
@@ -289,6 +322,7 @@ class vtkICP:
         p.check_mean_distance = int(self.CheckMeanDistance)
         p.max_mean_distance = self.MaximumMeanDistance
         p.min_normal_dot = self.MinNormalDot
+        p.rotate_source_normals = int(self.RotateSourceNormals)
         return p
 
     def InternalUpdate(self):

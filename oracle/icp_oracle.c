@@ -704,13 +704,13 @@ static inline void xform(const double T[16], const double in[3], double out[3])
 int64_t orc_correspond(const orc_mesh* m, const float* src, int64_t np, const float* src_normals,
   const double T[16], int64_t step, double max_dist, double min_dot, int use_grid, int nthreads,
   float* origin, float* origin_normal, float* closest, float* normal, int32_t* cell, double* dist,
-  int64_t* src_index, int32_t* kind)
+  int64_t* src_index, int32_t* kind, int rotate_sn)
 {
   if (step < 1)
     step = 1;
   int64_t nk = (np + step - 1) / step;
   char* ok = (char*)calloc((size_t)nk + 1, 1);
-  float* tmp = (float*)malloc(sizeof(float) * 9 * (size_t)(nk + 1));
+  float* tmp = (float*)malloc(sizeof(float) * 12 * (size_t)(nk + 1));
   int32_t* tc = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(nk + 1));
   double* td = (double*)malloc(sizeof(double) * (size_t)(nk + 1));
 #ifdef _OPENMP
@@ -729,11 +729,30 @@ int64_t orc_correspond(const orc_mesh* m, const float* src, int64_t np, const fl
     double sd = orc_closest_point_and_normal(m, x, use_grid, n, cp, &c, &kd);
     float nf[3] = { (float)n[0], (float)n[1], (float)n[2] };
     int accept = fabs(sd) < max_dist;
+    float sf[3] = { 0.f, 0.f, 0.f };
+    if (src_normals)
+    {
+      /* as written the reference uses the source normal unrotated (.cxx:284,299);
+       * rotate_sn is the opt-in corrected mode: the normal of the moved point, T's 3x3
+       * applied in fp64 and rounded to float */
+      double sx = src_normals[3 * i], sy = src_normals[3 * i + 1], sz = src_normals[3 * i + 2];
+      if (rotate_sn)
+      {
+        sf[0] = (float)(T[0] * sx + T[1] * sy + T[2] * sz);
+        sf[1] = (float)(T[4] * sx + T[5] * sy + T[6] * sz);
+        sf[2] = (float)(T[8] * sx + T[9] * sy + T[10] * sz);
+      }
+      else
+      {
+        sf[0] = (float)sx;
+        sf[1] = (float)sy;
+        sf[2] = (float)sz;
+      }
+    }
     if (accept && src_normals)
     {
-      double dn = (double)nf[0] * (double)src_normals[3 * i] +
-        (double)nf[1] * (double)src_normals[3 * i + 1] +
-        (double)nf[2] * (double)src_normals[3 * i + 2];
+      double dn = (double)nf[0] * (double)sf[0] + (double)nf[1] * (double)sf[1] +
+        (double)nf[2] * (double)sf[2];
       accept = dn > min_dot;
     }
     if (c < 0)
@@ -741,9 +760,10 @@ int64_t orc_correspond(const orc_mesh* m, const float* src, int64_t np, const fl
     ok[k] = (char)accept;
     for (int a = 0; a < 3; a++)
     {
-      tmp[9 * k + a] = (float)x[a];
-      tmp[9 * k + 3 + a] = (float)cp[a];
-      tmp[9 * k + 6 + a] = nf[a];
+      tmp[12 * k + a] = (float)x[a];
+      tmp[12 * k + 3 + a] = (float)cp[a];
+      tmp[12 * k + 6 + a] = nf[a];
+      tmp[12 * k + 9 + a] = sf[a];
     }
     tc[2 * k] = (int32_t)c;
     tc[2 * k + 1] = kd;
@@ -756,11 +776,11 @@ int64_t orc_correspond(const orc_mesh* m, const float* src, int64_t np, const fl
       continue;
     for (int a = 0; a < 3; a++)
     {
-      origin[3 * n + a] = tmp[9 * k + a];
-      closest[3 * n + a] = tmp[9 * k + 3 + a];
-      normal[3 * n + a] = tmp[9 * k + 6 + a];
+      origin[3 * n + a] = tmp[12 * k + a];
+      closest[3 * n + a] = tmp[12 * k + 3 + a];
+      normal[3 * n + a] = tmp[12 * k + 6 + a];
       if (origin_normal && src_normals)
-        origin_normal[3 * n + a] = src_normals[3 * (k * step) + a];
+        origin_normal[3 * n + a] = tmp[12 * k + 9 + a];
     }
     if (cell)
       cell[n] = tc[2 * k];
@@ -897,7 +917,7 @@ int orc_solve(int metric, int precision, int64_t n, const float* s, const float*
 int orc_icp_run(const orc_mesh* m, const float* src, int64_t np, const float* src_normals,
   int metric, int max_iter, int64_t max_landmarks, double max_dist, int check_mean,
   double max_mean, double min_dot, int precision, int use_grid, int nthreads, double T[16],
-  int* iters, double* mean_dist, int64_t* last_n)
+  int* iters, double* mean_dist, int64_t* last_n, int rotate_sn)
 {
   for (int i = 0; i < 16; i++)
     T[i] = (i % 5 == 0) ? 1.0 : 0.0;
@@ -917,7 +937,7 @@ int orc_icp_run(const orc_mesh* m, const float* src, int64_t np, const float* sr
   for (int it = 0; it < max_iter; it++)
   {
     int64_t n = orc_correspond(m, src, np, sn, T, step, max_dist, min_dot, use_grid, nthreads, o,
-      on, l, ln, NULL, NULL, NULL, NULL);
+      on, l, ln, NULL, NULL, NULL, NULL, rotate_sn);
     *last_n = n;
     if (check_mean)
     {

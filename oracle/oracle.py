@@ -46,7 +46,7 @@ def _load():
     lib.orc_correspond.argtypes = [
         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, _f64p, C.c_int64, C.c_double, C.c_double,
         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-        C.c_void_p, C.c_void_p]
+        C.c_void_p, C.c_void_p, C.c_int]
     lib.orc_correspond_f64.restype = C.c_int64
     lib.orc_correspond_f64.argtypes = [
         C.c_void_p, C.c_void_p, C.c_int64, _f64p, C.c_int64, C.c_double, C.c_int, C.c_int,
@@ -58,7 +58,7 @@ def _load():
     lib.orc_icp_run.argtypes = [
         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_double,
         C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, _f64p,
-        C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     lib.orc_num_threads.restype = C.c_int
     return lib
 
@@ -126,8 +126,9 @@ class Mesh:
         return sd, n, cp, int(c[0]), int(k[0])
 
     def correspond(self, src, T=None, step=1, max_dist=10.0, src_normals=None, min_dot=0.0,
-                   grid=True, threads=None):
-        """vtkPolyDataCorrespondenceFilter restated; rows in index order."""
+                   grid=True, threads=None, rotate_normals=False):
+        """vtkPolyDataCorrespondenceFilter restated; rows in index order.  rotate_normals: the
+        opt-in corrected mode (source normals rotated by T; the reference does not)."""
         src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
         sn = None if src_normals is None else np.ascontiguousarray(
             src_normals, np.float32).reshape(-1, 3)
@@ -143,7 +144,8 @@ class Mesh:
             self.h, _ptr(src), len(src), _ptr(sn), T.reshape(-1), step, float(max_dist),
             float(min_dot), int(grid), int(threads or num_threads()), _ptr(out["origin"]),
             _ptr(out["origin_normal"]), _ptr(out["closest"]), _ptr(out["normal"]),
-            _ptr(out["cell"]), _ptr(out["dist"]), _ptr(out["src_index"]), _ptr(out["kind"]))
+            _ptr(out["cell"]), _ptr(out["dist"]), _ptr(out["src_index"]), _ptr(out["kind"]),
+            int(bool(rotate_normals)))
         return {k: v[:n] for k, v in out.items()}
 
     def correspond_f64(self, src, T=None, step=1, max_dist=10.0, grid=True, threads=None):
@@ -163,7 +165,7 @@ class Mesh:
 
     def icp(self, src, metric=1, max_iter=50, max_landmarks=200, max_dist=10.0,
             check_mean=False, max_mean=0.01, src_normals=None, min_dot=0.0, precision=64,
-            grid=True, threads=None):
+            grid=True, threads=None, rotate_normals=False):
         """vtkICP::InternalUpdate restated. Returns (T, iterations, mean_distance, status, n)."""
         src = np.ascontiguousarray(src, np.float32).reshape(-1, 3)
         sn = None if src_normals is None else np.ascontiguousarray(
@@ -176,7 +178,7 @@ class Mesh:
             self.h, _ptr(src), len(src), _ptr(sn), int(metric), int(max_iter),
             int(max_landmarks), float(max_dist), int(check_mean), float(max_mean),
             float(min_dot), int(precision), int(grid), int(threads or num_threads()), T,
-            C.byref(it), C.byref(md), C.byref(ln))
+            C.byref(it), C.byref(md), C.byref(ln), int(bool(rotate_normals)))
         return T.reshape(4, 4), it.value, md.value, st, ln.value
 
 

@@ -14,7 +14,7 @@ src = synth.apply(T0, pts.astype(np.float64) + noise)
 Tinv = np.linalg.inv(T0)
 seq = [np.eye(4), np.eye(4), 0.5 * (np.eye(4) + Tinv), Tinv, Tinv, Tinv @ synth.rigid(rz=0.01), Tinv]
 ctxs = []
-for local, persistent in ((True, True), (False, False), (False, True)):
+for local, persistent in ((True, 1), (False, 3), (False, 1)):
     c = icpx.Context(0)
     c.set_group_width(1); c.set_local(local); c.set_persistent(persistent)
     c.set_target(xyz, tri); c.set_source(src)
