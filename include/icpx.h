@@ -125,6 +125,25 @@ extern "C"
     double max_dist, double min_dot, int use_source_normals, double* sums_host,
     double* sums_device);
 
+  /* icpx_accumulate for callers that cannot allocate device memory: code under HIP graph
+   * capture, tight serving loops that re-register a few hundred landmarks per frame,
+   * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The call
+   * allocates nothing: the kept points are ordered, searched and summed in a static device
+   * array inside the library (about 2.1 MiB, one copy per GPU, held until the process
+   * ends).  The meshes are the context's (icpx_set_target / icpx_set_source, which do
+   * allocate, come first); the ICPX_NSUMS sums are left in the caller's device buffer
+   * sums_device, stream-ordered; arguments otherwise as icpx_accumulate.  Same sums, bit
+   * for bit, as icpx_accumulate gives for the same arguments.
+   * Limits: at most ICPX_STATIC_MAX_QUERIES kept points in this context's shard (more is
+   * ICPX_E_INVALID: use icpx_accumulate or a larger step), and the search tree of that size
+   * class must exist: one earlier icpx_accumulate call on this target with a step of the
+   * same size class (up to 4096 kept points, or more) builds it, otherwise ICPX_E_INVALID.
+   * Every call on one GPU, from any context, uses that GPU's one array: calls that overlap
+   * in time on one GPU race and must be serialised by the caller. */
+#define ICPX_STATIC_MAX_QUERIES 32768
+  int icpx_accumulate_static(icpx_ctx* ctx, int metric, const double T[16], int64_t step,
+    double max_dist, double min_dot, int use_source_normals, double* sums_device);
+
   /* The same search, returning the filter's outputs instead of sums: accepted
    * rows in ascending source-index order, compacted on the device.  Any output
    * pointer may be NULL.  Buffers must hold ceil(np/step) rows (this shard's

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -153,6 +154,53 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
   const double origin[3] = { ox, oy, oz };
   solve_and_publish(s, tot, metric, origin, check_mean, max_mean, ran, counters ? counters[7] : 0u,
     rec, seq);
+}
+
+// ---- icpx_accumulate_static: scratch that lives in the code object, not on the heap ----
+// Everything that entry point needs beyond the context's meshes and the caller's output: the
+// query order (keys, values, sort histograms), the ordered queries and the block partials.
+// One copy per GPU the library runs on, held until the process ends; every call on a GPU
+// uses that GPU's copy, so calls that overlap on one GPU race.
+constexpr int64_t STATIC_MAX_QUERIES = ICPX_STATIC_MAX_QUERIES; // kept source points per call
+constexpr int STATIC_MAX_BLOCKS = 1024;       // finalize blocks (partials)
+constexpr size_t st_align(size_t b)
+{
+  return (b + 255) & ~(size_t)255;
+}
+constexpr size_t ST_KEYS = st_align(sizeof(uint64_t) * STATIC_MAX_QUERIES);
+constexpr size_t ST_VALS = st_align(sizeof(uint32_t) * STATIC_MAX_QUERIES);
+constexpr size_t ST_SORT_WORDS = 16384; // histograms + scan levels of the radix sort
+constexpr size_t ST_SORT = st_align(sizeof(uint32_t) * ST_SORT_WORDS);
+constexpr size_t ST_VEC3 = st_align(sizeof(float) * 3 * STATIC_MAX_QUERIES);
+constexpr size_t ST_I32 = st_align(sizeof(int32_t) * STATIC_MAX_QUERIES);
+constexpr size_t ST_PART = st_align(sizeof(double) * STATIC_MAX_BLOCKS * ICPX_NSUMS);
+constexpr size_t ST_OFF_KA = 0, ST_OFF_KB = ST_OFF_KA + ST_KEYS, ST_OFF_VA = ST_OFF_KB + ST_KEYS,
+                 ST_OFF_VB = ST_OFF_VA + ST_VALS, ST_OFF_SORT = ST_OFF_VB + ST_VALS,
+                 ST_OFF_QPOS = ST_OFF_SORT + ST_SORT, ST_OFF_QSN = ST_OFF_QPOS + ST_VEC3,
+                 ST_OFF_QK = ST_OFF_QSN + ST_VEC3, ST_OFF_HINT = ST_OFF_QK + ST_I32,
+                 ST_OFF_PART = ST_OFF_HINT + ST_I32, ST_BYTES = ST_OFF_PART + ST_PART;
+static __device__ __align__(256) unsigned char scratch[ST_BYTES]; // (about 2.1 MiB)
+
+// The array's address on each device (the name above is only a host-side handle: host code
+// passes these pointers, never the name).  Filled by icpx_create with that device current.
+constexpr int ST_MAX_DEVICES = 64;
+static unsigned char* g_scratch_ptr[ST_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+static int scratch_for_device(int device)
+{
+  if (device < 0 || device >= ST_MAX_DEVICES)
+    return ICPX_OK; // (beyond the table: the static entry point reports it)
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[device])
+    return ICPX_OK;
+  void* p = nullptr;
+  const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+  if (e != hipSuccess || !p)
+    return fail(ICPX_E_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", device,
+      hipGetErrorString(e));
+  g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+  return ICPX_OK;
 }
 
 // From this many queries on, a pass that finds certificates checks them in a kernel of its
@@ -576,7 +624,9 @@ extern "C" int icpx_create(icpx_ctx** out, int device)
     return fail(ICPX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
   }
   c->stream = c->own_stream;
-  int rc = dev_alloc(&c->d_partials, (int64_t)c->max_blocks * ICPX_NSUMS);
+  int rc = scratch_for_device(device);
+  if (!rc)
+    rc = dev_alloc(&c->d_partials, (int64_t)c->max_blocks * ICPX_NSUMS);
   if (!rc)
     rc = dev_alloc(&c->d_sums, ICPX_NSUMS);
   if (!rc && hipHostMalloc((void**)&c->h_sums, sizeof(double) * ICPX_NSUMS) != hipSuccess)
@@ -1986,6 +2036,120 @@ extern "C" int icpx_accumulate(icpx_ctx* c, int metric, const double T[16], int6
     HIPCHK(hipStreamSynchronize(st));
     std::memcpy(sums_host, c->h_sums, sizeof(double) * ICPX_NSUMS);
   }
+  return ICPX_OK;
+}
+
+// icpx_accumulate for callers that cannot allocate.  Nothing here calls hipMalloc, hipFree or
+// a routine that does: the kept points are ordered, searched and summed in the static array
+// above, the meshes are the context's, the sums go to the caller's device buffer.
+extern "C" int icpx_accumulate_static(icpx_ctx* c, int metric, const double T[16], int64_t step,
+  double max_dist, double min_dot, int use_sn, double* sums_device)
+{
+  int rc = check_call(c, T, metric, use_sn);
+  if (rc)
+    return rc;
+  if (!sums_device)
+    return fail(ICPX_E_INVALID, "icpx_accumulate_static: sums_device is null");
+  if (c->nt == 0)
+    return fail(ICPX_E_INVALID, "no target set");
+  if (c->np == 0)
+    return fail(ICPX_E_INVALID, "no source set");
+  if (step < 1)
+    return fail(ICPX_E_INVALID, "step must be >= 1");
+  const int64_t nk = (c->np + step - 1) / step;
+  const int64_t k0 = nk * c->rank / c->world, k1 = nk * (c->rank + 1) / c->world;
+  const int64_t nq = k1 - k0;
+  if (nq > STATIC_MAX_QUERIES)
+    return fail(ICPX_E_INVALID,
+      "icpx_accumulate_static: %lld kept source points, the static scratch holds %lld at most "
+      "(use icpx_accumulate, or a larger step)",
+      (long long)nq, (long long)STATIC_MAX_QUERIES);
+  if (rs_scratch_words(nq) > (int64_t)ST_SORT_WORDS)
+    return fail(ICPX_E_INVALID, "icpx_accumulate_static: sort scratch too small");
+  if (c->device >= ST_MAX_DEVICES || !g_scratch_ptr[c->device])
+    return fail(ICPX_E_INVALID, "icpx_accumulate_static: no scratch address for device %d",
+      c->device);
+  // the search tree of this size class is built (allocated) by the first ordinary pass
+  const int G = nq <= 4096 ? 64 : 8;
+  const int slot = G == 64 ? 4 : 1;
+  const Heap& h = c->heaps[slot];
+  if (nq > 0 && !h.built)
+    return fail(ICPX_E_INVALID,
+      "icpx_accumulate_static: the %d-ary search tree is not built yet; one icpx_accumulate "
+      "call with the same step builds it (that call allocates)", G);
+  HIPCHK(hipSetDevice(c->device));
+  c->run_active = false;
+  hipStream_t st = c->stream;
+  if (nq == 0)
+  {
+    HIPCHK(hipMemsetAsync(sums_device, 0, sizeof(double) * ICPX_NSUMS, st));
+    return ICPX_OK;
+  }
+  unsigned char* base = g_scratch_ptr[c->device];
+  uint64_t* ka = reinterpret_cast<uint64_t*>(base + ST_OFF_KA);
+  uint64_t* kb = reinterpret_cast<uint64_t*>(base + ST_OFF_KB);
+  uint32_t* va = reinterpret_cast<uint32_t*>(base + ST_OFF_VA);
+  uint32_t* vb = reinterpret_cast<uint32_t*>(base + ST_OFF_VB);
+  uint32_t* sortscr = reinterpret_cast<uint32_t*>(base + ST_OFF_SORT);
+  float* qpos = reinterpret_cast<float*>(base + ST_OFF_QPOS);
+  float* qsn = reinterpret_cast<float*>(base + ST_OFF_QSN);
+  int32_t* qk = reinterpret_cast<int32_t*>(base + ST_OFF_QK);
+  int32_t* hint = reinterpret_cast<int32_t*>(base + ST_OFF_HINT);
+  double* partials = reinterpret_cast<double*>(base + ST_OFF_PART);
+
+  rc = set_transform(c, T, 0);
+  if (rc)
+    return rc;
+  // the array keeps the last call's contents: everything read below is written first (the
+  // sort clears its own histograms, k_gather_queries writes every query's slot, hints start
+  // at -1, every finalize block writes its partial)
+  k_morton_points<<<nblk(nq, 256), 256, 0, st>>>(c->d_src, k0, step, nq, c->box, ka, va);
+  const int which = radix_sort_pairs(ka, va, kb, vb, nq, 63, sortscr, st);
+  k_gather_queries<<<nblk(nq, 256), 256, 0, st>>>(
+    c->d_src, c->d_srcn, which ? vb : va, k0, step, nq, qpos, qsn, qk, hint);
+  set_cap(c, max_dist);
+  Search2Args a;
+  a.qpos = qpos;
+  a.nq = nq;
+  a.T = xf_ref(c);
+  a.nodes = h.nodes;
+  a.tree = h.t;
+  a.tverts = c->d_tverts;
+  a.tid = c->d_tid;
+  a.nt = c->nt;
+  a.hint = hint;
+  a.use_hint = 0;
+  a.scene_max = c->scene_max;
+  a.cap2 = c->cap2;
+  a.cert = nullptr;
+  a.widen = 0.f;
+  if (G == 64)
+    launch_search2<64>(a, nblk(nq, 256 / 64), st);
+  else
+    launch_search2<8>(a, nblk(nq, 256 / 8), st);
+  FinalArgs f;
+  fill_final(c, f, max_dist, min_dot, use_sn, use_sn || metric == ICPX_METRIC_PLANE_TO_PLANE);
+  f.qpos = qpos;
+  f.qsn = f.qsn ? qsn : nullptr;
+  f.qk = qk;
+  f.nq = nq;
+  f.hint = hint;
+  f.partials = partials;
+  int grid = (int)nblk(nq, FIN_THREADS); // (the same shape as icpx_accumulate's: same sums)
+  if (grid > c->num_cus * 3)
+    grid = c->num_cus * 3;
+  if (grid > std::min(c->max_blocks, STATIC_MAX_BLOCKS))
+    grid = std::min(c->max_blocks, STATIC_MAX_BLOCKS);
+  if (metric == 0)
+    k_finalize<0, false><<<grid, FIN_THREADS, 0, st>>>(f);
+  else if (metric == 1)
+    k_finalize<1, false><<<grid, FIN_THREADS, 0, st>>>(f);
+  else
+    k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
+  // (no counters, no policy figures, and the context's certificates are left as they are)
+  k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(partials, grid, sums_device, &c->d_state->done,
+    nullptr, nullptr, c->d_state->T, c->d_state->cert_T, nullptr, 0, c->cap2, nullptr);
+  LAUNCHCHK();
   return ICPX_OK;
 }
 

@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("ICPX_LIB") or os.path.join(_HERE, "libicpx.so")  # (I
 SYMBOLS = (
     "icpx_last_error", "icpx_device_count", "icpx_create", "icpx_destroy", "icpx_set_stream",
     "icpx_synchronize", "icpx_set_target", "icpx_set_source", "icpx_set_shard", "icpx_get_origin",
-    "icpx_accumulate", "icpx_correspond", "icpx_correspond_f64", "icpx_solve", "icpx_default_params",
+    "icpx_accumulate", "icpx_accumulate_static", "icpx_correspond", "icpx_correspond_f64", "icpx_solve", "icpx_default_params",
     "icpx_set_allreduce", "icpx_run",
     "icpx_run_begin", "icpx_run_enqueue", "icpx_run_update", "icpx_run_end",
     "icpx_point_normals",
@@ -77,6 +77,7 @@ def load():
     lib.icpx_set_shard.argtypes = [vp, ci, ci]
     lib.icpx_get_origin.argtypes = [vp, vp]
     lib.icpx_accumulate.argtypes = [vp, ci, vp, i64, dbl, dbl, ci, vp, vp]
+    lib.icpx_accumulate_static.argtypes = [vp, ci, vp, i64, dbl, dbl, ci, vp]
     lib.icpx_correspond.argtypes = [vp, vp, i64, dbl, dbl, ci, vp, vp, vp, vp, vp, vp, vp,
                                     C.POINTER(i64)]
     lib.icpx_correspond_f64.argtypes = [vp, vp, i64, dbl, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
@@ -318,6 +319,15 @@ class Context:
         _chk(load().icpx_accumulate(self._h, int(metric), _p(T), int(step), float(max_dist),
                                     float(min_dot), int(use_source_normals), _p(sums), None))
         return sums
+
+    def accumulate_static(self, metric, T, step, max_dist, min_dot, use_source_normals,
+                          device_ptr):
+        """icpx_accumulate_static: the same sums left at `device_ptr`, with no allocation (the
+        scratch is a static device array in the library; at most 32768 kept points)."""
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        _chk(load().icpx_accumulate_static(self._h, int(metric), _p(T), int(step),
+                                           float(max_dist), float(min_dot),
+                                           int(use_source_normals), C.c_void_p(device_ptr)))
 
     def correspond(self, T=None, step=1, max_dist=10.0, min_dot=0.0, use_source_normals=False):
         """The correspondence filter's outputs: accepted rows in ascending source index."""
