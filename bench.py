@@ -1,17 +1,23 @@
 #!/usr/bin/env python
 """Benchmark of the ICP hot path on MI355X.
 
-A step is one ICP iteration over the whole source cloud: fused closest-point
-search + fp64 partial sums on the GPU, one all-reduce of the 40-double sum vector
-(RCCL, stream-ordered, when more than one rank), solve and transform update on the
-device.  The timed region is the first K iterations of a registration started cold
-(identity transform, no winners carried over), so the expensive first pass is inside it.
+A STEP is one whole registration, i.e. one vtkICP::Update(): the workload's fixed number of
+ICP iterations (50, vtkICP's default and the north star's figure) from a cold start (identity
+transform, no winners carried over).  Every iteration is a fused closest-point search + fp64
+partial sums on the GPU, one all-reduce of the 40-double sum vector (RCCL, stream-ordered,
+when more than one rank), solve and transform update on the device.  --steps K times exactly
+K such registrations after --warmup W untimed ones; because a step always contains the same
+work (one cold pass, a few displaced passes, the converged rest), `value` does not depend on
+K.  The K registrations are also timed one by one: median and spread are in `config`.
 
-Workload (default c3, the configuration the headline metric names): the synthetic
+Workloads.  c3 (default, the configuration the headline metric names): the synthetic
 1,000,000-triangle bumpy torus against 1,000,000 area-uniform surface samples moved by
 rotY 5 deg + 1 % of the diagonal, symmetric (plane-to-plane) metric, every point used.
-With N ranks each rank holds its own 1M-point scan of the same surface (weak scaling);
-the target and its BVH are replicated.
+c4: 10,000,000 triangles against 16,000,000 noisy samples, point-to-plane.
+Scaling.  weak (default): every rank holds its own scan of the replicated surface.
+strong (--scaling strong; what config 4 asks for): every rank loads the SAME cloud and
+searches its contiguous share of it (icpx_set_shard); rank 0 then repeats the registration
+alone on the whole cloud and requires the same 4x4 to 1e-11.
 
 Prints ONE JSON line (rank 0).
 """
@@ -27,17 +33,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+ITERATIONS = 50        # per registration: vtkICP's default (ICP/vtkICP.cxx:31), the north star's run
 
 
-def algorithmic_bytes_per_corr(nv, nt, nq, rows=False):
-    """Compulsory traffic per searched point: its 12-byte source point (+ a 36-byte result
-    row when rows are written) plus one amortised read of the search structure per pass:
-    points, indices, BVH nodes at 4 triangles per leaf, face / edge / vertex normals."""
-    structure = 12 * nv + 12 * nt + 32 * (2 * nt / 4 - 1) + 12 * nt + 36 * nt + 12 * nv
-    return 12.0 + (36.0 if rows else 0.0) + structure / nq
+def structure_bytes(nv, nt):
+    """One read of the search structure: points, indices, BVH nodes at 4 triangles per leaf,
+    face / edge / vertex normals."""
+    return 12 * nv + 12 * nt + 32 * (2 * nt / 4 - 1) + 12 * nt + 36 * nt + 12 * nv
 
 
-def make_workload(name, rank, synth):
+def make_workload(name, rank, synth, own_scan):
     if name == "c3":
         c = synth.config_c3()
     elif name == "c4":
@@ -48,7 +53,7 @@ def make_workload(name, rank, synth):
         c = synth.config_c3(nu=200, nv=100, npts=50_000)
     else:
         raise SystemExit("unknown workload %s" % name)
-    if rank > 0:  # every rank scans the same surface with its own samples
+    if own_scan and rank > 0:  # weak scaling: every rank scans the same surface with its own samples
         xyz, tri = c["target_xyz"], c["target_tri"]
         pts, f, fn = synth.sample_surface(xyz, tri, len(c["source_xyz"]), seed=synth.SEED + rank)
         M = c["truth"]
@@ -66,9 +71,10 @@ def make_workload(name, rank, synth):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20, help="timed registrations")
+    ap.add_argument("--warmup", type=int, default=3, help="untimed registrations first")
     ap.add_argument("--workload", default="c3")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--width", type=int, default=0, help="lanes per query (0 = library default)")
     ap.add_argument("--leaf", type=int, default=0, help="triangles per leaf (0 = library default)")
     ap.add_argument("--local", type=int, default=-1,
@@ -105,7 +111,8 @@ def main():
     if args.one_device:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1 or args.force_collective:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         if args.backend == "nccl":
@@ -114,10 +121,12 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    c = make_workload(args.workload, rank, synth)
-    nq, nt, nv = len(c["source_xyz"]), len(c["target_tri"]), len(c["target_xyz"])
+    strong = args.scaling == "strong"
+    c = make_workload(args.workload, rank, synth, own_scan=not strong)
+    npts, nt, nv = len(c["source_xyz"]), len(c["target_tri"]), len(c["target_xyz"])
     metric = c["metric"]
-    sh = ShardedICP(device=local, rank=0, world=1)  # the local scan is this rank's whole shard
+    # weak: the local scan is this rank's whole shard; strong: a share of the one cloud
+    sh = ShardedICP(device=local, rank=rank if strong else 0, world=world if strong else 1)
     if args.width:
         sh.ctx.set_group_width(args.width)
     if args.leaf:
@@ -126,22 +135,23 @@ def main():
         sh.ctx.set_local(args.local)
     sh.set_target(c["target_xyz"], c["target_tri"])
     sh.set_source(c["source_xyz"], c["source_normals"])
-    origin = sh.ctx.origin
     build_s = sh.ctx.build_seconds
+    nq_rank = npts if not strong else (npts * (rank + 1) // world - npts * rank // world)
+    nq_job = npts * world if not strong else npts
 
     params = icpx.default_params()
     params.metric = metric
-    params.max_landmarks = nq          # every point is a landmark
+    params.max_landmarks = npts         # every point is a landmark
     params.max_distance = c["max_dist"]
-    params.check_mean_distance = 0     # exactly K iterations
+    params.check_mean_distance = 0      # exactly ITERATIONS iterations
+    params.max_iterations = ITERATIONS
 
-    def registration(iters):
-        """iters ICP iterations from a cold start; returns (T, iterations, last mean distance)."""
-        if iters <= 0:
-            return np.eye(4), 0, 0.0
-        params.max_iterations = iters
+    def registration():
+        """One vtkICP::Update(): ITERATIONS iterations from a cold start."""
         T, it, md, status = sh.run_device(params, force_collective=args.force_collective)
-        return T, it, md
+        if it != ITERATIONS:
+            raise SystemExit("registration stopped after %d of %d iterations" % (it, ITERATIONS))
+        return T, md
 
     def fence():
         sh.ctx.synchronize()
@@ -150,34 +160,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    registration(args.warmup)
+    for _ in range(args.warmup):
+        registration()
     sh.ctx.set_timing(0 if args.no_kernel_timing else 2)  # the search kernels only
     fence()
+    each = []
     t0 = time.perf_counter()
-    T, n_iter, mean_d = registration(args.steps)
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        T, mean_d = registration()     # (returns when the last iteration's transform is back)
+        each.append(time.perf_counter() - t1)
     fence()
     elapsed = time.perf_counter() - t0
-    s_ms, s_n, f_ms, f_n = sh.ctx.get_timing()
+    pass_ms, pass_kind, pass_hinted = sh.ctx.get_pass_timings()
     sh.ctx.set_timing(False)
-    if n_iter != args.steps:
-        raise SystemExit("registration stopped after %d of %d iterations" % (n_iter, args.steps))
-    n_acc = sh.ctx.accumulate(metric, T, 1, c["max_dist"])[0]  # outside the timed region
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    one_rank_check = None
+    if strong and world > 1 and rank == 0:
+        # the same registration on one rank with the whole cloud: the sharded sums must
+        # lead to the same transform
+        one = icpx.Context(local)
+        one.set_target(c["target_xyz"], c["target_tri"])
+        one.set_source(c["source_xyz"], c["source_normals"])
+        T1 = one.run(params)[0]
+        one_rank_check = float(np.abs(T - T1).max() / np.abs(T1).max())
+        one.close()
+        if one_rank_check > 1e-11:
+            raise SystemExit("sharded and one-rank transforms differ by %.3e" % one_rank_check)
+
     if rank == 0:
-        total = float(nq) * world * args.steps
-        b_alg = algorithmic_bytes_per_corr(nv, nt, nq)
-        search_ms = s_ms / max(s_n, 1)
-        achieved = b_alg * nq / (search_ms * 1e-3) / 1e9 if s_n else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                traffic = json.load(fh).get("k_search_hbm_bytes_per_launch")
+        total = float(nq_job) * ITERATIONS * args.steps
+        each = np.array(each)
         out = {
             "metric": "point-to-mesh correspondences/sec (ICP iterations/sec in config)",
             "value": total / elapsed,
@@ -187,61 +205,96 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s: %d-triangle bumpy torus vs %d source points per GPU, %s metric, "
-                            "every point used, cold-start registration" % (
-                                args.workload, nt, nq,
-                                ("point-to-point", "point-to-plane", "symmetric")[metric]),
-                "icp_iterations_per_s": args.steps / elapsed,
-                "accepted_last_iteration": int(n_acc),
+                "workload": "%s: %d-triangle bumpy torus vs %d source points %s, %s metric, every "
+                            "point used; one step = one cold-start registration of %d iterations" % (
+                                args.workload, nt, npts,
+                                "sharded over the ranks" if strong else "per GPU",
+                                ("point-to-point", "point-to-plane", "symmetric")[metric],
+                                ITERATIONS),
+                "iterations_per_step": ITERATIONS,
+                "icp_iterations_per_s": ITERATIONS * args.steps / elapsed,
+                "registration_ms_median": float(1e3 * np.median(each)),
+                "registration_ms_min": float(1e3 * each.min()),
+                "registration_ms_max": float(1e3 * each.max()),
                 "mean_distance_last_iteration": float(mean_d),
                 "residual_vs_truth": float(np.abs(T @ c["truth"] - np.eye(4)).max())
                 if "truth" in c else None,
                 "target_build_seconds": build_s,
-                "finalize_kernel_ms_avg": (f_ms / f_n) if f_n else None,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_search",
-                "kernel_note": "one launch = the search kernels of one pass on the library's "
-                               "stream (k_certify for large clouds, k_search_local or k_search3w, "
-                               "then k_fallback / k_search3p and k_contested), HIP events around them",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_correspondence": b_alg,
-                "kernel_ms_avg": search_ms,
-                "launches": int(s_n),
+                "world_size": dist.get_world_size() if collective else 1,
+                "backend": dist.get_backend() if collective else "none",
+                "one_rank_check_rel": one_rank_check,
             },
         }
+        if len(pass_ms) == ITERATIONS * args.steps:
+            # rank 0's search kernels, pass by pass (HIP events riding on the first and the
+            # last search kernel of every pass, on the library's stream)
+            pm = pass_ms.reshape(args.steps, ITERATIONS)
+            cold = float(np.median(pm[:, 0]))                       # k_search3w, cold start
+            steady = float(np.median(pm[:, ITERATIONS // 2:]))      # converged passes
+            b_struct = structure_bytes(nv, nt)
+            b_cold = 12.0 * nq_rank + b_struct     # every point once + one read of the structure
+            b_steady = 20.0 * nq_rank              # point 12 B + certificate 4 B + winner 4 B
+            ach_cold = b_cold / (cold * 1e-3) / 1e9
+            ach_steady = b_steady / (steady * 1e-3) / 1e9
+            search_total = float(pm.sum(1).mean())
+            out["config"]["cold_pass_corr_per_s"] = nq_rank / (cold * 1e-3)
+            out["config"]["steady_pass_corr_per_s"] = nq_rank / (steady * 1e-3)
+            out["config"]["search_kernels_ms_per_registration"] = search_total
+            out["roofline"] = {
+                "bound": "hbm",
+                "kernel": "k_search3w<4,false> (the cold pass: one walk per wavefront over the "
+                          "whole cloud; the largest single share of a registration's GPU time)",
+                "achieved": ach_cold,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach_cold / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": b_cold,
+                "kernel_ms": cold,
+                "launches": int(args.steps),
+                "phases": {
+                    "cold_pass": {"kernels": "k_search3w + k_contested", "ms": cold,
+                                  "algorithmic_bytes": b_cold, "achieved_GBs": ach_cold,
+                                  "frac": ach_cold / HBM_PEAK_GBS},
+                    "steady_pass": {"kernels": "k_certify (large clouds) + k_search_local + "
+                                               "k_fallback + k_contested",
+                                    "ms": steady, "algorithmic_bytes": b_steady,
+                                    "achieved_GBs": ach_steady,
+                                    "frac": ach_steady / HBM_PEAK_GBS},
+                },
+            }
+        else:
+            out["roofline"] = {"bound": "hbm", "kernel": "k_search3w", "achieved": None,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle as orc
             mesh = orc.Mesh(c["target_xyz"], c["target_tri"])
-            nsample = min(nq, 1_000_000)
+            nsample = min(npts, 1_000_000 if nt <= 2_000_000 else 250_000)
             threads = orc.num_threads()
             t0 = time.perf_counter()
-            rows = mesh.correspond(c["source_xyz"][:nsample], step=1, max_dist=c["max_dist"],
-                                   src_normals=None if c["source_normals"] is None
-                                   else c["source_normals"][:nsample], grid=True, threads=threads)
+            mesh.correspond(c["source_xyz"][:nsample], step=1, max_dist=c["max_dist"],
+                            src_normals=None if c["source_normals"] is None
+                            else c["source_normals"][:nsample], grid=True, threads=threads)
             dt = time.perf_counter() - t0
             out["cpu_baseline"] = {
                 "value": nsample / dt,
                 "unit": "correspondences/s",
                 "cores": threads,
                 "kind": "port",
-                "sample": "one correspondence-filter pass (identity transform) over the first %d "
-                          "source points of the same workload, bucket-grid locator restatement of "
-                          "the vtkSMPTools path, %.1f s" % (nsample, dt),
+                "sample": "one correspondence-filter pass at the start pose (what the GPU's cold "
+                          "pass does: compare config.cold_pass_corr_per_s) over the first %d source "
+                          "points of the same workload, bucket-grid locator restatement of the "
+                          "vtkSMPTools path, %.1f s" % (nsample, dt),
             }
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
-    if world > 1 or args.force_collective:
+    if collective:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -288,6 +288,9 @@ struct icpx_ctx
   int64_t local_passes = 0, tree_passes = 0, nbr_builds = 0, nbr_total = 0;
   int64_t certify_passes = 0; // passes whose certificates were checked by k_certify
   int64_t split_passes = 0;   // passes that enqueued both tree kernels over the leftovers
+  int64_t split_wave = 0, split_pool = 0; // ... of a run, by the kernel the list's length picked
+  bool last_split = false;                // the pass enqueued last was such a pass
+  bool pass_split[4] = { false, false, false, false }; // ... and the run's passes, by record slot
   // lane-per-query kernel's tie bookkeeping, sized for q3_cap queries
   int64_t q3_cap = 0;
   int32_t* d_cand = nullptr;
@@ -415,7 +418,7 @@ struct ScopedTimer
   {
     if (!c->timing || (c->timing == 2 && which != 0))
       return;
-    if (c->pending.size() >= 4096)
+    if (c->pending.size() >= 16384)
     {
       (void)hipStreamSynchronize(c->stream);
       resolve_timing(c);
@@ -808,9 +811,9 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
   }
   else if (what == 4)
   {
-    int64_t v[7] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
-      c->nbr_total, c->certify_passes, c->split_passes };
-    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 7));
+    int64_t v[9] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
+      c->nbr_total, c->certify_passes, c->split_passes, c->split_wave, c->split_pool };
+    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 9));
     return ICPX_OK;
   }
   else if (what == 3 && c->d_ovf_best)
@@ -1453,6 +1456,7 @@ static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, uns
     // the pooled lanes: both are enqueued, and the one whose side of nq/2 the list's length
     // is on does the work (the other's blocks return after one read).
     c->split_passes++;
+    c->last_split = true;
     Search3Args lo = a, hi = a;
     lo.list_hi = a.nq / 2;
     hi.list_lo = a.nq / 2;
@@ -1812,6 +1816,7 @@ static void set_cap(icpx_ctx* c, double max_dist)
 static int run_search(icpx_ctx* c)
 {
   c->last_local = false;
+  c->last_split = false;
   c->certs_live = c->pass_certs && c->hint_valid; // (what the last pass left)
   c->pass_certs = false;
   const int G = pick_width(c);
@@ -1995,6 +2000,7 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
       p.max_mean_distance, c->d_rec + slot, ++c->rec_seq, c->d_ticket, c->cap2);
     c->slot_seq[slot] = c->rec_seq;
     c->pass_local[slot] = c->last_local;
+    c->pass_split[slot] = c->last_split;
     c->run_it++;
   }
   else
@@ -2439,6 +2445,19 @@ extern "C" int icpx_run_begin(icpx_ctx* c, const icpx_params* p)
 // enqueued, iteration i-2's record (32 bytes, copied behind its solve) is awaited.  That
 // keeps the queue fed, bounds the passes enqueued after the run stopped (they return at
 // once on the device), and brings the residual the shortcut's policy looks at.
+// Which of the two tree kernels enqueued over a large cloud's leftovers did the work in the
+// pass behind record `slot` (diagnostic counts; the list's length is only known afterwards).
+static void tally_split(icpx_ctx* c, int slot)
+{
+  if (!c->pass_split[slot])
+    return;
+  c->pass_split[slot] = false;
+  if ((int64_t)c->h_rec[slot].fallback >= c->nq / 2)
+    c->split_wave++;
+  else
+    c->split_pool++;
+}
+
 static int run_catch_up(icpx_ctx* c)
 {
   if (c->run_it < 2)
@@ -2472,6 +2491,7 @@ static int run_catch_up(icpx_ctx* c)
   if (r.done)
     c->run_done_known = true;
   note_pass(c, r.n, r.mean, (double)r.fallback, c->pass_local[slot]);
+  tally_split(c, slot);
   return ICPX_OK;
 }
 
@@ -2514,6 +2534,7 @@ extern "C" int icpx_run_update(icpx_ctx* c, const double* sums_device)
   LAUNCHCHK();
   c->slot_seq[slot] = c->rec_seq;
   c->pass_local[slot] = c->last_local;
+    c->pass_split[slot] = c->last_split;
   c->run_it++;
   return ICPX_OK;
 }
@@ -2528,6 +2549,9 @@ extern "C" int icpx_run_end(icpx_ctx* c, double T_out[16], int* iterations_out,
   HIPCHK(hipMemcpyAsync(&h, c->d_state, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->run_active = false;
+  for (int s = 0; s < 4; s++) // (the last two iterations' records were not looked at yet)
+    if (c->h_rec[s].seq == c->slot_seq[s])
+      tally_split(c, s);
   if (T_out)
     std::memcpy(T_out, h.T, sizeof(h.T));
   if (iterations_out)

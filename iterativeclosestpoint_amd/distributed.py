@@ -71,6 +71,7 @@ class ShardedICP:
         import torch
 
         self.rank, self.world, self.group = rank, world, group
+        self.exit_on_error = True  # multi-rank runs: a local failure ends this process
         self.ctx = icpx.Context(device)
         self.ctx.set_shard(rank, world)
         self.sums_dev = None
@@ -104,6 +105,21 @@ class ShardedICP:
         ar = make_allreduce(self.group)
         return sums if ar is None else ar(sums)
 
+    def _local_failure(self, exc, multi):
+        """A rank whose library call failed must not leave the others waiting in the
+        all-reduce: close the run, and in a multi-rank job end this process (the peers'
+        collectives then fail instead of blocking for ever)."""
+        import os
+        import sys
+        try:
+            self.ctx.run_end()          # clears the run; waits for what was enqueued
+        except Exception:
+            pass
+        if multi and self.exit_on_error:
+            sys.stderr.write("ShardedICP rank %d: %s; leaving the job\n" % (self.rank, exc))
+            sys.stderr.flush()
+            os._exit(70)
+
     def run_device(self, params, force_collective=False):
         """The whole loop without a host round trip per iteration: search and sums on the
         GPU, all-reduce of the 40 sums on the device (stream-ordered, RCCL), solve and
@@ -123,13 +139,17 @@ class ShardedICP:
                 return self.ctx.run(params)
         ptr = self.sums_dev.data_ptr()
         self.ctx.run_begin(params)
-        with torch.cuda.stream(self.stream):
-            for _ in range(params.max_iterations):
-                if self.ctx.run_enqueue(ptr):
-                    break
-                if multi:
-                    all_reduce_device(self.sums_dev, self.group)
-                self.ctx.run_update(ptr)
+        try:
+            with torch.cuda.stream(self.stream):
+                for _ in range(params.max_iterations):
+                    if self.ctx.run_enqueue(ptr):
+                        break
+                    if multi:
+                        all_reduce_device(self.sums_dev, self.group)
+                    self.ctx.run_update(ptr)
+        except BaseException as exc:
+            self._local_failure(exc, dist.get_world_size(self.group) > 1)
+            raise
         return self.ctx.run_end()
 
     def run(self, metric=1, max_iterations=50, max_landmarks=200, max_distance=10.0,

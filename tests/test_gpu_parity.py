@@ -634,6 +634,70 @@ def test_large_target_c4_sample(icpx, synth, oracle):
     assert np.abs(rows["normal"][pick] - ref["normal"]).max() <= 1e-6
 
 
+def test_full_size_c4(icpx, synth, oracle):
+    """The target run itself: 10M triangles, 16M noisy points, point-to-plane, through the
+    default kernels (no knobs).  (1) The 4x4 after two iterations and every 3200th row of the
+    first two passes against golden vectors the CPU oracle produced on the same inputs
+    (tools/make_c4_golden.py).  (2) The 50-iteration registration against the ground truth.
+    (3) The light certificate kernel, and both tree kernels enqueued over a large cloud's
+    leftovers, did run.  (4) At the converged pose: a 5000-row sample against the oracle run
+    here, and properties of all 16M rows."""
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "c4_two_iterations.npz"))
+    c = synth.config_c4()
+    n = len(c["source_xyz"])
+    assert n == 16_000_000 and len(c["target_tri"]) == 10_000_000
+    ctx = icpx.Context(0)
+    ctx.set_target(c["target_xyz"], c["target_tri"])
+    ctx.set_source(c["source_xyz"])
+    p = icpx.default_params()
+    p.metric, p.max_landmarks, p.max_distance = 1, n, c["max_dist"]
+    p.max_iterations = 2
+    T2, it, mean, st = ctx.run(p)
+    assert it == 2 and rel_err(T2, gold["T2"]) <= 1e-9
+    p.max_iterations = 1
+    assert rel_err(ctx.run(p)[0], gold["T1"]) <= 1e-9
+    stride = int(gold["sample_stride"])
+    for k in (0, 1):
+        rows = ctx.correspond(gold["pose%d" % k], step=1, max_dist=c["max_dist"])
+        assert len(rows["cell"]) == int(gold["n%d" % k]) == n
+        pick = gold["src_index%d" % k]
+        assert np.array_equal(pick, np.arange(0, n, stride))
+        for key in ("cell", "dist", "closest"):
+            assert np.array_equal(rows[key][pick], gold["%s%d" % (key, k)]), (k, key)
+        assert np.abs(rows["normal"][pick] - gold["normal%d" % k]).max() <= 1e-6
+        d = np.linalg.norm(rows["origin"].astype(np.float64) - rows["closest"], axis=1)
+        assert abs(d.mean() - float(gold["mean%d" % k])) <= 1e-12
+        del rows, d
+    p.max_iterations = 50
+    T, it, mean, st = ctx.run(p)
+    assert it == 50 and st == icpx.RUN_MAX_ITERATIONS
+    assert np.abs(T @ c["truth"] - np.eye(4)).max() < 3e-5   # the noise floor of the scan
+    stats = ctx.debug_stats()
+    assert stats["certify_passes"] >= 40, stats   # certificates checked by the light kernel
+    assert stats["split_wave"] >= 1 and stats["split_pool"] >= 30, stats
+    rows = ctx.correspond(T, step=1, max_dist=c["max_dist"])
+    assert len(rows["cell"]) == n and np.array_equal(rows["src_index"], np.arange(n))
+    pick = (np.arange(5_000) * 3137 + 11).astype(np.int64)
+    mesh = oracle.Mesh(c["target_xyz"], c["target_tri"])
+    ref = mesh.correspond(c["source_xyz"][pick], T=T, step=1, max_dist=c["max_dist"], grid=True)
+    for key in ("cell", "dist", "closest"):
+        assert np.array_equal(rows[key][pick], ref[key]), key
+    assert np.abs(rows["normal"][pick] - ref["normal"]).max() <= 1e-6
+    # every emitted point lies on its triangle's plane to rounding, at the emitted distance
+    P0 = c["target_xyz"][c["target_tri"][rows["cell"], 0]].astype(np.float64)
+    P1 = c["target_xyz"][c["target_tri"][rows["cell"], 1]].astype(np.float64)
+    P2 = c["target_xyz"][c["target_tri"][rows["cell"], 2]].astype(np.float64)
+    nrm = np.cross(P1 - P0, P2 - P0)
+    del P1, P2
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    off = np.abs(np.einsum("ij,ij->i", rows["closest"].astype(np.float64) - P0, nrm))
+    assert off.max() <= 1e-6
+    del P0, nrm, off
+    d = np.linalg.norm(rows["origin"].astype(np.float64) - rows["closest"].astype(np.float64), axis=1)
+    assert np.abs(d - rows["dist"]).max() <= 1e-6
+    assert abs(d.mean() - mean) <= 1e-6            # the loop's last mean distance is one solve old
+
+
 def test_device_loop_with_rccl_collective(icpx, synth, small):
     """The multi-GPU driver's loop on one rank: search -> all-reduce of the sums through
     the nccl (RCCL) backend -> solve, all ordered on torch's stream, against icpx_run."""
@@ -949,7 +1013,7 @@ def test_registration_demo_from_a_file(icpx, synth, tmp_path, capsys):
         assert worst < tol, (metric, out)
 
 
-def _sharded_rank(rank, world, port, metric, out):
+def _sharded_rank(rank, world, port, metric, out, landmarks=None):
     """One rank of test_sharded_device_loop_two_ranks (spawned)."""
     import torch.distributed as dist
     from iterativeclosestpoint_amd import icpx as ix, synth as sy
@@ -967,7 +1031,7 @@ def _sharded_rank(rank, world, port, metric, out):
     sh.set_target(xyz, tri)
     sh.set_source(src, sn)
     p = ix.default_params()
-    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = metric, 12, len(src), 10.0
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = metric, 12, landmarks or len(src), 10.0
     p.check_mean_distance, p.max_mean_distance = 1, 1e-7
     T, it, mean, st = sh.run_device(p)
     out.put((rank, T, it, mean, st))
@@ -1121,6 +1185,44 @@ def test_in_place_edits_reach_the_device(icpx, synth, small):
     assert np.abs(M1 @ shift - M0).max() < 1e-3 and np.abs(M1 - M0).max() > 0.04
     To = mesh.icp(src.GetPoints(), metric=1, max_iter=50, max_landmarks=500)[0]
     assert rel_err(M1, To) <= 1e-6
+
+
+@pytest.mark.parametrize("landmarks", (1, 7))
+def test_sharded_loop_with_an_empty_shard(icpx, synth, landmarks):
+    """More ranks than kept points: with MaximumNumberOfLandmarks = 1 one point is kept, rank 0's
+    shard is empty and the run stops for want of rows on both ranks, as on one rank; with 7
+    (eight kept points, four per rank) the two ranks register like one."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_rank, args=(r, 2, port, 1, q, landmarks)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    xyz, tri = synth.bumpy_torus(200, 100)
+    pts, f, fn = synth.sample_surface(xyz, tri, 50_001, seed=9)
+    src = synth.apply(synth.rigid(ry=3.0, t=(0.01, 0.0, 0.02)), pts)
+    one = icpx.Context(0)
+    one.set_target(xyz, tri)
+    one.set_source(src)
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = 1, 12, landmarks, 10.0
+    p.check_mean_distance, p.max_mean_distance = 1, 1e-7
+    T, it, mean, st = one.run(p)
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:]
+    assert (res[0][2], res[0][4]) == (it, st)
+    assert rel_err(res[0][1], T) <= 1e-11
+    if landmarks == 1:
+        assert st == icpx.RUN_TOO_FEW and it == 0 and np.array_equal(T, np.eye(4))
+    else:
+        assert it >= 1 and st in (icpx.RUN_MAX_ITERATIONS, icpx.RUN_CONVERGED)
 
 
 def test_abi_rejects_bad_input(icpx):
