@@ -318,6 +318,65 @@ __device__ __forceinline__ float note_screened(float sec2, double d2, double bes
   return d2 <= bound ? sec2 : fminf(sec2, __double2float_rd(d2) * 0.999999f);
 }
 
+// The same bookkeeping when the nearest loser is to be known by name as well (a walk that
+// screens every triangle it meets): r1 / r1id, the smallest such lower bound and the triangle
+// it belongs to; r2, the smallest among all the others.  ring0: the ring's first member.
+__device__ __forceinline__ void note_loser(float& r1, int32_t& r1id, float& r2, float v, int32_t id)
+{
+  if (v < r1)
+  {
+    r2 = r1;
+    r1 = v;
+    r1id = id;
+  }
+  else
+    r2 = fminf(r2, v);
+}
+__device__ __forceinline__ void note_screened_named(float& r1, int32_t& r1id, float& r2, double d2,
+  int32_t s, double best, double bound, double tau, int cnt, int32_t ring0)
+{
+  if (d2 < best)
+  {
+    const double r = sqrt(d2) + tau;
+    if (r * r < best && cnt > 0)
+    {
+      // the ring is about to be emptied: its members were at least the old minimum away,
+      // the first of them exactly that
+      const float v = __double2float_rd(best) * 0.999999f;
+      note_loser(r1, r1id, r2, v, ring0);
+      if (cnt > 1)
+        r2 = fminf(r2, v);
+    }
+  }
+  else if (!(d2 <= bound))
+    note_loser(r1, r1id, r2, __double2float_rd(d2) * 0.999999f, s);
+}
+
+// A single winner whose nearest loser is next to nothing farther away (a query whose foot
+// point lies a hair inside an edge: the triangle across that edge) gets no certificate worth
+// having from make_certificate, pass after pass.  If the loser after that one is well
+// away, the winner and its nearest loser are kept as a set of two instead (see cert_encode):
+// the returned certificate then covers every triangle outside that pair.  pair: the set was
+// chosen; `floor`: a single-winner certificate at least this large is kept as it is.
+__device__ __forceinline__ float make_certificate_pair(int cnt, double best, float r1, float r2,
+  int32_t r1id, float minraw, float minlin, double tau, float eabs, double cap2, float floor_,
+  bool& pair)
+{
+  pair = false;
+  const float single = make_certificate(cnt, best, r1, minraw, minlin, tau, eabs, cap2);
+  if (cnt != 1 || r1id < 0 || single >= floor_)
+    return single;
+  // (cnt = 2: the encoding of a set; the arithmetic is the single winner's with the nearest
+  // loser left out of "the others")
+  const float both = make_certificate(2, best, r2, minraw, minlin, tau, eabs, cap2);
+  if (both > single && both > 0.f)
+  {
+    pair = true;
+    return both;
+  }
+  return single;
+}
+
 // fp32 lower bound of the squared distance to a box; never above the true value
 __device__ __forceinline__ float box_lb(float lox, float loy, float loz, float hix, float hiy,
   float hiz, float xf, float yf, float zf, float eabs)
@@ -627,6 +686,8 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
   uint32_t n = 1, trail = 0;
   float lbleaf = 0.f;
   float sec2 = INFINITY, minraw = INFINITY; // for the certificate (make_certificate)
+  float sec3 = INFINITY;                    // ... and the nearest loser by name (note_screened_named)
+  int32_t sec_id = -1;
   float widen = 0.f;                        // margin by which the walk looks farther (widen_of)
   bool have = false, fin = false, need_bt = false, atleaf = false;
   bool dry = false; // the pool has run out (same for every lane of the wavefront)
@@ -665,7 +726,21 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
       if (f && !tie && !ovf)
         a.hint[q] = (cnt == 1) ? ring[0][tid] : -1;
       if (f && a.cert)
-        a.cert[q] = make_certificate(cnt, best, sec2, minraw, INFINITY, tau, eabs, a.cap2);
+      {
+        // (a certificate that the next few moves of this size would use up is not worth
+        // more than none)
+        bool pair;
+        a.cert[q] = make_certificate_pair(cnt, best, sec2, sec3, sec_id, minraw, INFINITY, tau,
+          eabs, a.cap2, fmaxf(widen, 4.f * eabs), pair);
+        if (pair)
+        {
+          // the set of two, for later passes (this pass's winner is settled: the loser is
+          // beyond the tie tolerance)
+          a.cand[q * RING3 + 0] = ring[0][tid];
+          a.cand[q * RING3 + 1] = sec_id;
+          a.cand[q * RING3 + 2] = -1;
+        }
+      }
       const unsigned long long mt = __ballot(tie);
       if (mt)
       {
@@ -721,6 +796,8 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
           cnt = 0;
           hs_used = -1;
           sec2 = INFINITY;
+          sec3 = INFINITY;
+          sec_id = -1;
           minraw = INFINITY;
           best = DBL_MAX;
           bound = DBL_MAX;
@@ -850,7 +927,8 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
           const double d2 = tri_d2_screen(x, P0, P1, P2);
           // (the start triangle, met again, is in the ring or has lost already)
           if ((int32_t)s != hs_used)
-            sec2 = note_screened(sec2, d2, best, bound, tau, cnt);
+            note_screened_named(sec2, sec_id, sec3, d2, (int32_t)s, best, bound, tau, cnt,
+              ring[0][tid]);
           if (d2 < best)
             set_best(d2);
           if (d2 <= bound && (int32_t)s != hs_used)
