@@ -1785,6 +1785,7 @@ static int run_search3(icpx_ctx* c)
     wide.scene_max = c->scene_max;
     wide.cap2 = c->cap2;
     wide.cert = a.cert;
+    wide.cand = c->d_cand;
     wide.widen = a.cert ? a.widen_max : 0.f;
     widep = &wide;
   }
@@ -1848,6 +1849,7 @@ static int run_search(icpx_ctx* c)
     a.scene_max = c->scene_max;
     a.cap2 = c->cap2;
     a.cert = nullptr;
+    a.cand = nullptr;
     a.widen = 0.f;
     ScopedTimer tm(c, 0);
     switch (G)
@@ -2128,6 +2130,7 @@ extern "C" int icpx_accumulate_static(icpx_ctx* c, int metric, const double T[16
   a.scene_max = c->scene_max;
   a.cap2 = c->cap2;
   a.cert = nullptr;
+  a.cand = nullptr;
   a.widen = 0.f;
   if (G == 64)
     launch_search2<64>(a, nblk(nq, 256 / 64), st);

@@ -26,6 +26,7 @@
 // ICP/vtkImplicitPolyDataDistance2.cxx:375.
 #pragma once
 #include "query.hpp"
+#include "cert.hpp"
 #include <float.h>
 
 namespace icpx
@@ -305,8 +306,12 @@ struct Search2Args
   int use_hint;
   float scene_max; // largest |coordinate| of the target's bounds
   double cap2;     // square of the distance beyond which nothing needs to be found (DBL_MAX: none)
-  float* cert;     // certificates (see local.hpp), or null: a query that ends here with nothing
-                   // within the cap gets a far certificate, any other none (0)
+  float* cert;     // certificates (see local.hpp), or null.  A query that ends here with nothing
+                   // within the cap gets a far certificate.  With one wavefront per query
+                   // (G = 64) a single winner gets a near one (or, its nearest loser being a hair
+                   // behind, the pair as a set), and two to RING3 tied contenders a set
+                   // certificate; otherwise none (0)
+  int32_t* cand;   // [nq][RING3] contender sets behind set certificates (or null: no sets)
   float widen;     // margin by which the walk looks beyond its bound, so that a far certificate
                    // is worth something (0 when certificates are not kept)
 };
@@ -351,6 +356,10 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
   int32_t hs_used = -1; // the hinted triangle already sits in the ring
   int top = 0;
   float minlb = INFINITY; // smallest lower bound (squared) of anything this lane turned away
+  // for a near certificate: the boxes this lane turned away, the nearest triangle it screened
+  // and turned away (by name), and the nearest after that
+  float minbox = INFINITY, lose1 = INFINITY, lose2 = INFINITY;
+  int32_t lose_id = -1;
 
   auto set_best = [&](double nb) {
     // older ring entries were all above the old minimum; if the new bound is
@@ -439,6 +448,7 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
       if (lbf > boundf)
       {
         minlb = fminf(minlb, lbf);
+        minbox = fminf(minbox, lbf);
         continue;
       }
       const uint32_t n = (uint32_t)e;
@@ -455,7 +465,10 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
       const float lb = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * 0.99999952f;
       const bool push = lb <= boundf; // an empty box gives +inf and boundf is finite
       if (!push)
+      {
         minlb = fminf(minlb, lb);
+        minbox = fminf(minbox, lb);
+      }
       // distinct integer keys: the bound's bits, lowered by G ulps, with the lane number in
       // the low bits (so the stored bound never exceeds the computed one)
       const uint32_t lbits = __float_as_uint(lb);
@@ -486,10 +499,27 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
       minlb = fminf(minlb, __double2float_rd(d2) * 0.999999f);
     const double m = group_min<G>(d2);
     if (m < best)
+    {
+      if (G == 64 && a.cert && cnt > 0 && j == 0)
+      {
+        // a new minimum that empties the ring leaves its members behind as losers, at least
+        // the old minimum away (the first of them exactly that)
+        const double r = sqrt(m) + tau;
+        if (r * r < best)
+        {
+          const float v = __double2float_rd(best) * 0.999999f;
+          note_loser(lose1, lose_id, lose2, v, ring[g][0]);
+          if (cnt > 1)
+            lose2 = fminf(lose2, v);
+        }
+      }
       set_best(m);
+    }
     // the hinted triangle is met again during the walk: it is in the ring already, or out
     // of the race for good if the ring restarted since
     const bool cand = d2 <= bound && (int32_t)s != hs_used;
+    if (G == 64 && a.cert && d2 < INFINITY && !(d2 <= bound) && (int32_t)s != hs_used)
+      note_loser(lose1, lose_id, lose2, __double2float_rd(d2) * 0.999999f, (int32_t)s);
     const unsigned long long bal = __ballot(cand);
     const uint32_t gm = (G == 64) ? 0u : ((uint32_t)(bal >> gbase) & GM);
     const int k = (G == 64) ? __popcll(bal) : __popc(gm);
@@ -512,6 +542,43 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
 
   if (active)
   {
+    // a near certificate, from what the 64 lanes turned away between them (before the ring
+    // is resolved: a set certificate keeps its members)
+    float nearc = 0.f;
+    bool have_near = false;
+    if constexpr (G == 64)
+    {
+      if (a.cert && !flushed && cnt >= 1 && cnt <= RING3 && (cnt == 1 || a.cand))
+      {
+        const float m1 = (float)group_min<G>((double)lose1);
+        const unsigned long long who = __ballot(lose1 == m1);
+        const int leader = __ffsll((long long)who) - 1;
+        const int32_t id1 = m1 < INFINITY ? __shfl(lose_id, leader, 64) : -1;
+        const float m2 = (float)group_min<G>((double)(lane == leader ? lose2 : lose1));
+        const float mb = (float)group_min<G>((double)minbox);
+        // (these box bounds carry their rounding allowances already)
+        const float dbox = __builtin_amdgcn_sqrtf(mb) * 0.999999f;
+        have_near = true;
+        if (cnt == 1)
+        {
+          bool pair;
+          nearc = make_certificate_pair(1, best, m1, m2, a.cand ? id1 : -1, INFINITY, dbox, tau,
+            eabs, a.cap2, fmaxf(a.widen, 4.f * eabs), pair);
+          if (pair && j == 0)
+          {
+            a.cand[q * RING3 + 0] = ring[g][0];
+            a.cand[q * RING3 + 1] = id1;
+            a.cand[q * RING3 + 2] = -1;
+          }
+        }
+        else
+        {
+          nearc = make_certificate(cnt, best, m1, INFINITY, dbox, tau, eabs, a.cap2);
+          if (nearc != 0.f && j <= cnt && j < RING3)
+            a.cand[q * RING3 + j] = j < cnt ? ring[g][j] : -1;
+        }
+      }
+    }
     int32_t win;
     if (cnt == 1 && !flushed)
       win = ring[g][0]; // a single contender needs no exact evaluation here
@@ -536,7 +603,7 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
     {
       a.hint[q] = win;
       if (a.cert)
-        a.cert[q] = far;
+        a.cert[q] = have_near ? nearc : far;
     }
   }
 }

@@ -226,25 +226,6 @@ __device__ __forceinline__ float widen_of(const Search3Args& a, const Xf& T, con
   return fminf(fmaxf(8.f * mv, 2.f * eabs), fmaxf(a.widen_max, 2.f * eabs));
 }
 
-constexpr int RING3 = 8;
-
-// A positive certificate's last mantissa bit says what stands while it lasts: 0, the single
-// winner; 1, the set of contenders kept in cand[] (a query on an edge or a vertex shared by
-// several triangles has them at the same distance for good): the winner among them is
-// worked out anew every pass by exact evaluation, but no search is needed to know that
-// nobody else is in the race.  (The value gives way by up to two units in the last place.)
-__device__ __forceinline__ float cert_encode(float c, bool set)
-{
-  const uint32_t b = __float_as_uint(c);
-  if (!(c > 0.f) || b < 8u)
-    return 0.f;
-  return __uint_as_float(((b - 2u) & ~1u) | (set ? 1u : 0u));
-}
-__device__ __forceinline__ bool cert_is_set(float c)
-{
-  return c > 0.f && (__float_as_uint(c) & 1u) != 0u;
-}
-
 // The list of queries whose certificates failed (k_certify) is kept in this many segments,
 // with counts this many words apart.
 constexpr int CERTIFY_SEGS = 32;
@@ -274,107 +255,6 @@ __device__ __forceinline__ void push_certified_sets(bool isset, int64_t q, const
       cnt += (cnt == i && m[i] >= 0) ? 1 : 0;
     tie_list[base + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
   }
-}
-
-// The certificate of a finished query.  cnt: contenders (1: a single winner; 2..RING3: a set,
-// all in the ring); best: the winner's screened squared distance; sec2: lower bound of the
-// squared distance of every screened triangle that is not (or no longer) in the ring;
-// minraw: smallest raw squared box distance (box_d2) among the boxes turned away;
-// minlin: smallest lower bound, as a distance, of triangles turned away by cheap bounds.
-__device__ __forceinline__ float make_certificate(int cnt, double best, float sec2, float minraw,
-  float minlin, double tau, float eabs, double cap2)
-{
-  const bool near = cnt >= 1 && cnt <= RING3;
-  // (a raw box distance exceeds the true one by at most sqrt(3) eabs)
-  const float dbox = __builtin_amdgcn_sqrtf(minraw) * 0.999999f - 1.7320509f * eabs;
-  const float others = fminf(fminf(dbox, minlin), __builtin_amdgcn_sqrtf(sec2) * 0.999999f);
-  // what the screened distance of the winner may be off by: a few units in the last place
-  // of the squared coordinates, i.e. ~0.02 eabs^2 / distance, never more than eabs
-  const float dw = __double2float_ru(sqrt(near ? best : cap2));
-  const float slop = fminf(eabs, 0.2f * eabs * eabs / fmaxf(dw, 1e-30f)) + 2.1f * (float)tau;
-  float c = 0.f;
-  if (near)
-    c = others - dw * 1.000001f - slop;
-  else if (cnt == 0 && cap2 < 1e300)
-    c = -(others - dw * 1.000001f - slop);
-  // (a near certificate must be positive, a far one negative; infinities mean nothing was
-  // ever turned away, which only a mesh without triangles does)
-  if (near)
-    return (c > 0.f && c < 1e30f) ? cert_encode(c, cnt >= 2) : 0.f;
-  return (c < 0.f && c > -1e30f) ? c : 0.f;
-}
-
-// A screened triangle joins the bookkeeping of the certificate: one that is turned away is
-// at least its distance away; a new minimum that empties the ring leaves contenders behind
-// that were at least the old minimum away.  (Call before set_best / the ring's update.)
-__device__ __forceinline__ float note_screened(float sec2, double d2, double best, double bound,
-  double tau, int cnt)
-{
-  if (d2 < best)
-  {
-    const double r = sqrt(d2) + tau;
-    return (r * r < best && cnt > 0) ? fminf(sec2, __double2float_rd(best) * 0.999999f) : sec2;
-  }
-  return d2 <= bound ? sec2 : fminf(sec2, __double2float_rd(d2) * 0.999999f);
-}
-
-// The same bookkeeping when the nearest loser is to be known by name as well (a walk that
-// screens every triangle it meets): r1 / r1id, the smallest such lower bound and the triangle
-// it belongs to; r2, the smallest among all the others.  ring0: the ring's first member.
-__device__ __forceinline__ void note_loser(float& r1, int32_t& r1id, float& r2, float v, int32_t id)
-{
-  if (v < r1)
-  {
-    r2 = r1;
-    r1 = v;
-    r1id = id;
-  }
-  else
-    r2 = fminf(r2, v);
-}
-__device__ __forceinline__ void note_screened_named(float& r1, int32_t& r1id, float& r2, double d2,
-  int32_t s, double best, double bound, double tau, int cnt, int32_t ring0)
-{
-  if (d2 < best)
-  {
-    const double r = sqrt(d2) + tau;
-    if (r * r < best && cnt > 0)
-    {
-      // the ring is about to be emptied: its members were at least the old minimum away,
-      // the first of them exactly that
-      const float v = __double2float_rd(best) * 0.999999f;
-      note_loser(r1, r1id, r2, v, ring0);
-      if (cnt > 1)
-        r2 = fminf(r2, v);
-    }
-  }
-  else if (!(d2 <= bound))
-    note_loser(r1, r1id, r2, __double2float_rd(d2) * 0.999999f, s);
-}
-
-// A single winner whose nearest loser is next to nothing farther away (a query whose foot
-// point lies a hair inside an edge: the triangle across that edge) gets no certificate worth
-// having from make_certificate, pass after pass.  If the loser after that one is well
-// away, the winner and its nearest loser are kept as a set of two instead (see cert_encode):
-// the returned certificate then covers every triangle outside that pair.  pair: the set was
-// chosen; `floor`: a single-winner certificate at least this large is kept as it is.
-__device__ __forceinline__ float make_certificate_pair(int cnt, double best, float r1, float r2,
-  int32_t r1id, float minraw, float minlin, double tau, float eabs, double cap2, float floor_,
-  bool& pair)
-{
-  pair = false;
-  const float single = make_certificate(cnt, best, r1, minraw, minlin, tau, eabs, cap2);
-  if (cnt != 1 || r1id < 0 || single >= floor_)
-    return single;
-  // (cnt = 2: the encoding of a set; the arithmetic is the single winner's with the nearest
-  // loser left out of "the others")
-  const float both = make_certificate(2, best, r2, minraw, minlin, tau, eabs, cap2);
-  if (both > single && both > 0.f)
-  {
-    pair = true;
-    return both;
-  }
-  return single;
 }
 
 // fp32 lower bound of the squared distance to a box; never above the true value
@@ -967,7 +847,7 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
 // stragglers of a converged pass) is served one WAVEFRONT per query instead, over the
 // 64-ary tree of search2.hpp (a few steps of 64 box tests each); a long list by the
 // pooled lanes.  Same results either way.
-constexpr uint32_t FALLBACK_SMALL = 16384;
+constexpr uint32_t FALLBACK_SMALL = 98304;
 
 template <int L>
 __global__ __launch_bounds__(256) void k_fallback(Search3Args a, Search2Args w)
