@@ -167,6 +167,30 @@ extern "C"
     double* origin, double* closest, double* normal, int32_t* cell, double* dist,
     int64_t* src_index, int64_t* n_out);
 
+  /* First intersection of each of n line segments p1 -> p2 (3n doubles each) with the target
+   * mesh, and the pseudo-normal there.  Replaces
+   * vtkImplicitPolyDataIntersection::IntersectWithLine
+   * (ICP/vtkImplicitPolyDataIntersection.cxx:110-337) over the target of icpx_set_target:
+   * vtkCellLocator::IntersectWithLine with tolerance 1e-12 (:148; the smallest parameter t
+   * wins, equal t goes to the smallest cell id), EvaluatePosition at the hit (:169) and the
+   * face / edge-sum / angle-weighted vertex normal of the place it falls on (:172-304).
+   * Outputs per segment, any of which may be NULL, with the values the reference leaves in
+   * its arguments:
+   *   hit     1 / 0 (the function's return value);
+   *   ret     |p2 - p1| * t with the sign line :324 gives it: g has just been set to the
+   *           pseudo-normal there, so the value is always negated; NoValue (the length of the
+   *           target's bounds, :64) without a hit;
+   *   closest EvaluatePosition's closest point at the hit (0,0,0 without one);
+   *   normal  g: the pseudo-normal ((0,0,1) without a hit);
+   *   point   the intersection point itself (a local in the reference; 0 without a hit);
+   *   cell    index of the triangle hit in the array given to icpx_set_target (-1);
+   *   kind    0 face, 1 edge, 2 vertex: vtkDataObject::CELL / EDGE / VERTEX of the six-
+   *           argument overload (-1).
+   * ICPX_E_INVALID with "No polygons to intersect!" when no target is set. */
+  int icpx_intersect_lines(icpx_ctx* ctx, const double* p1, const double* p2, int64_t n,
+    int32_t* hit, double* ret, double* closest, double* normal, double* point, int32_t* cell,
+    int32_t* kind);
+
   /* Host-side solve of one iteration from (all-reduced) sums: 3x3 SVD for
    * point-to-point (ICP/icp/point2point.cxx:45-58), 6x6 LDL^T + Euler XYZ for
    * point-to-plane (ICP/icp/point2plane.cxx:88-106), 6x6 LDL^T + Rodrigues

@@ -14,6 +14,7 @@
 #include "state.hpp"
 #include "tables.hpp"
 #include "rows64.hpp"
+#include "intersect.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -233,6 +234,7 @@ struct icpx_ctx
   uint32_t* d_voff = nullptr;
   int32_t* d_vcell = nullptr;
   Box3 box;
+  double bounds_length = 0.0; // vtkDataSet::GetLength() of the target: the diagonal of its bounds
   double origin[3] = { 0, 0, 0 };
   Tree trees[5];  // exhaustive-exact kernel's level-array trees
   Heap heaps[5];  // group kernel's heap-ordered trees
@@ -1004,6 +1006,12 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   c->scene_max = 0.f;
   for (int a = 0; a < 3; a++)
     c->scene_max = std::fmax(c->scene_max, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+  {
+    double l2 = 0.0;
+    for (int a = 0; a < 3; a++)
+      l2 += ((double)hi[a] - (double)lo[a]) * ((double)hi[a] - (double)lo[a]);
+    c->bounds_length = std::sqrt(l2);
+  }
   {
     // typical edge length, from an even sample of the triangles (sizes the neighbour lists)
     const int64_t stride = std::max<int64_t>(1, nt / 8192);
@@ -2388,6 +2396,106 @@ extern "C" int icpx_correspond_f64(icpx_ctx* c, const double T[16], int64_t step
   HIPCHK(back(src_index, c->c_index, sizeof(int64_t) * n));
   HIPCHK(hipStreamSynchronize(st));
   *n_out = n;
+  return ICPX_OK;
+}
+
+// -------------------------------------------------------- line intersection ----
+// vtkImplicitPolyDataIntersection::IntersectWithLine for n segments at once
+// (ICP/vtkImplicitPolyDataIntersection.cxx:110-337), on the target's box tree.
+extern "C" int icpx_intersect_lines(icpx_ctx* c, const double* p1, const double* p2, int64_t n,
+  int32_t* hit, double* ret, double* closest, double* normal, double* point, int32_t* cell,
+  int32_t* kind)
+{
+  if (!c || !p1 || !p2)
+    return fail(ICPX_E_INVALID, "icpx_intersect_lines: null argument");
+  if (n < 0 || n >= (1ll << 31))
+    return fail(ICPX_E_INVALID, "icpx_intersect_lines: bad segment count %lld", (long long)n);
+  if (c->nt == 0 || !c->d_fn64 || !c->d_voff || !c->d_vcell)
+    return fail(ICPX_E_INVALID, "No polygons to intersect!");
+  for (int64_t i = 0; i < 3 * n; i++)
+    if (!std::isfinite(p1[i]) || !std::isfinite(p2[i]))
+      return fail(ICPX_E_INVALID, "icpx_intersect_lines: segment %lld is not finite",
+        (long long)(i / 3));
+  if (n == 0)
+    return ICPX_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const int L = c->leaf_size;
+  int rc = ensure_bin(c, L);
+  if (rc)
+    return rc;
+  const Bin& b = c->bins[(L == 1) ? 0 : (L == 2) ? 1 : 2];
+  hipStream_t st = c->stream;
+  double *d_p = nullptr, *d_out = nullptr; // {p1, p2}; {ret, closest, normal, point}
+  int32_t* d_i = nullptr;                  // {hit, cell, kind}
+  auto drop = [&]() {
+    dev_free(&d_p);
+    dev_free(&d_out);
+    dev_free(&d_i);
+  };
+  rc = dev_alloc(&d_p, 6 * n);
+  if (!rc)
+    rc = dev_alloc(&d_out, 10 * n);
+  if (!rc)
+    rc = dev_alloc(&d_i, 3 * n);
+  if (rc)
+  {
+    drop();
+    return rc;
+  }
+  hipError_t e = hipMemcpyAsync(d_p, p1, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(d_p + 3 * n, p2, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess)
+  {
+    IntersectArgs a;
+    a.p1 = d_p;
+    a.p2 = d_p + 3 * n;
+    a.n = n;
+    a.nodes = b.nodes;
+    a.tree = b.t;
+    a.tverts = c->d_tverts;
+    a.tid = c->d_tid;
+    a.nt = c->nt;
+    a.tri = c->d_tri;
+    a.xyz = c->d_xyz;
+    a.fn64 = c->d_fn64;
+    a.voff = c->d_voff;
+    a.vcell = c->d_vcell;
+    a.scene_max = c->scene_max;
+    a.novalue = c->bounds_length;
+    a.ret = d_out;
+    a.closest = d_out + n;
+    a.normal = d_out + 4 * n;
+    a.x = d_out + 7 * n;
+    a.hit = d_i;
+    a.cell = d_i + n;
+    a.kind = d_i + 2 * n;
+    const unsigned grid = nblk(n, ISECT_THREADS);
+    if (L == 1)
+      k_intersect_lines<1><<<grid, ISECT_THREADS, 0, st>>>(a);
+    else if (L == 2)
+      k_intersect_lines<2><<<grid, ISECT_THREADS, 0, st>>>(a);
+    else
+      k_intersect_lines<4><<<grid, ISECT_THREADS, 0, st>>>(a);
+    e = hipGetLastError();
+  }
+  auto back = [&](void* dst, const void* src, size_t bytes) {
+    if (e == hipSuccess && dst)
+      e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+  };
+  back(ret, d_out, sizeof(double) * n);
+  back(closest, d_out + n, sizeof(double) * 3 * n);
+  back(normal, d_out + 4 * n, sizeof(double) * 3 * n);
+  back(point, d_out + 7 * n, sizeof(double) * 3 * n);
+  back(hit, d_i, sizeof(int32_t) * n);
+  back(cell, d_i + n, sizeof(int32_t) * n);
+  back(kind, d_i + 2 * n, sizeof(int32_t) * n);
+  const hipError_t es = hipStreamSynchronize(st);
+  if (e == hipSuccess)
+    e = es;
+  drop();
+  if (e != hipSuccess)
+    return fail(ICPX_E_HIP, "icpx_intersect_lines failed: %s", hipGetErrorString(e));
   return ICPX_OK;
 }
 

@@ -26,7 +26,7 @@ SYMBOLS = (
     "icpx_accumulate", "icpx_accumulate_static", "icpx_correspond", "icpx_correspond_f64", "icpx_solve", "icpx_default_params",
     "icpx_set_allreduce", "icpx_run",
     "icpx_run_begin", "icpx_run_enqueue", "icpx_run_update", "icpx_run_end",
-    "icpx_point_normals",
+    "icpx_point_normals", "icpx_intersect_lines",
 )
 # ... and in include/icpx_dev.h (kernel variants, diagnostics, timing)
 DEV_SYMBOLS = (
@@ -81,6 +81,7 @@ def load():
     lib.icpx_correspond.argtypes = [vp, vp, i64, dbl, dbl, ci, vp, vp, vp, vp, vp, vp, vp,
                                     C.POINTER(i64)]
     lib.icpx_correspond_f64.argtypes = [vp, vp, i64, dbl, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    lib.icpx_intersect_lines.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]
     lib.icpx_solve.argtypes = [ci, vp, vp, vp, C.POINTER(i64), C.POINTER(dbl)]
     lib.icpx_default_params.argtypes = [C.POINTER(Params)]
     lib.icpx_default_params.restype = None
@@ -362,6 +363,23 @@ class Context:
             _p(out["normal"]), _p(out["cell"]), _p(out["dist"]), _p(out["src_index"]),
             C.byref(n)))
         return {k: v[:n.value] for k, v in out.items()}
+
+    def intersect_lines(self, p1, p2):
+        """First intersection of the segments p1[i] -> p2[i] with the target
+        (vtkImplicitPolyDataIntersection::IntersectWithLine, one call for all of them).
+        Returns a dict of arrays: hit, ret, closest, normal, point, cell, kind."""
+        p1 = np.ascontiguousarray(p1, np.float64).reshape(-1, 3)
+        p2 = np.ascontiguousarray(p2, np.float64).reshape(-1, 3)
+        if len(p1) != len(p2):
+            raise ValueError("p1 and p2 must have the same number of rows")
+        n = len(p1)
+        out = dict(hit=np.zeros(n, np.int32), ret=np.zeros(n), closest=np.zeros((n, 3)),
+                   normal=np.zeros((n, 3)), point=np.zeros((n, 3)), cell=np.zeros(n, np.int32),
+                   kind=np.zeros(n, np.int32))
+        _chk(load().icpx_intersect_lines(self._h, _p(p1), _p(p2), n, _p(out["hit"]),
+                                         _p(out["ret"]), _p(out["closest"]), _p(out["normal"]),
+                                         _p(out["point"]), _p(out["cell"]), _p(out["kind"])))
+        return out
 
     def set_allreduce(self, fn):
         """fn(numpy view of the NSUMS sums) -> None; called once per iteration inside run()."""

@@ -575,44 +575,17 @@ void orc_find_closest_grid(
   *dist2 = bd2;
 }
 
-/* -------------------- vtkImplicitPolyDataDistance2::ClosestPointAndNormal
- * kind: 0 face, 1 edge, 2 vertex.  awnorm starts from zero in the edge and
- * vertex cases (as in SharedEvaluate, vtkImplicitPolyDataDistance2.cxx:180).
- * Returns the signed distance; cell = -1 and the NoValue defaults when the
- * mesh has no usable triangle. */
-double orc_closest_point_and_normal(const orc_mesh* m, const double x[3], int use_grid,
-  double awnorm[3], double closestPoint[3], int64_t* cell_out, int* kind_out)
+/* The pseudo-normal at a point of cell cellId whose EvaluatePosition weights are w: the
+ * face normal, the normalised sum of the normals of the faces on the edge, or the
+ * angle-weighted sum over the faces at the vertex (ICP/vtkImplicitPolyDataDistance2.cxx:391-517;
+ * the same code in ICP/vtkImplicitPolyDataIntersection.cxx:172-304).  awnorm must come in as
+ * zero.  Returns the number of weights below the tolerance (0 face, 1 edge, 2 vertex). */
+static int pseudo_normal(const orc_mesh* m, int64_t cellId, const double w[3], double awnorm[3])
 {
-  double ret = sqrt((m->bmax[0] - m->bmin[0]) * (m->bmax[0] - m->bmin[0]) +
-    (m->bmax[1] - m->bmin[1]) * (m->bmax[1] - m->bmin[1]) +
-    (m->bmax[2] - m->bmin[2]) * (m->bmax[2] - m->bmin[2])); /* NoValue = GetLength() */
-  double g[3] = { 0.0, 0.0, 1.0 };
-  closestPoint[0] = closestPoint[1] = closestPoint[2] = 0.0;
-  awnorm[0] = awnorm[1] = awnorm[2] = 0.0;
-  *cell_out = -1;
-  *kind_out = -1;
-  if (m->nt == 0)
-    return ret;
-  double p[3], vlen2;
-  int64_t cellId;
-  if (use_grid)
-    orc_find_closest_grid(m, x, p, &cellId, &vlen2);
-  else
-    orc_find_closest_brute(m, x, p, &cellId, &vlen2);
-  if (cellId == -1)
-    return ret;
-  *cell_out = cellId;
-  ret = sqrt(vlen2);
-  for (int i = 0; i < 3; i++)
-    g[i] = (p[i] - x[i]) / (ret == 0. ? 1. : ret);
-
-  double dist2, w[3];
-  eval_cell(m, cellId, p, closestPoint, &dist2, w); /* :388 — evaluated at p, not at x */
   const int32_t* ids = &m->tri[3 * cellId];
   int count = 0;
   for (int i = 0; i < 3; i++)
     count += (fabs(w[i]) < ORC_TOL ? 1 : 0);
-  *kind_out = count;
   if (count == 0)
   {
     awnorm[0] = m->fnorm[3 * cellId];
@@ -652,7 +625,7 @@ double orc_closest_point_and_normal(const orc_mesh* m, const double x[3], int us
       if (fabs(w[i]) > ORC_TOL)
         a = ids[i];
     if (a == -1)
-      return ret;
+      return count;
     for (int64_t q = m->voff[a]; q < m->voff[a + 1]; q++)
     {
       int64_t c = m->vcell[q];
@@ -680,11 +653,170 @@ double orc_closest_point_and_normal(const orc_mesh* m, const double x[3], int us
     }
     normalize3(awnorm);
   }
+  return count;
+}
+
+/* -------------------- vtkImplicitPolyDataDistance2::ClosestPointAndNormal
+ * kind: 0 face, 1 edge, 2 vertex.  awnorm starts from zero in the edge and
+ * vertex cases (as in SharedEvaluate, vtkImplicitPolyDataDistance2.cxx:180).
+ * Returns the signed distance; cell = -1 and the NoValue defaults when the
+ * mesh has no usable triangle. */
+double orc_closest_point_and_normal(const orc_mesh* m, const double x[3], int use_grid,
+  double awnorm[3], double closestPoint[3], int64_t* cell_out, int* kind_out)
+{
+  double ret = sqrt((m->bmax[0] - m->bmin[0]) * (m->bmax[0] - m->bmin[0]) +
+    (m->bmax[1] - m->bmin[1]) * (m->bmax[1] - m->bmin[1]) +
+    (m->bmax[2] - m->bmin[2]) * (m->bmax[2] - m->bmin[2])); /* NoValue = GetLength() */
+  double g[3] = { 0.0, 0.0, 1.0 };
+  closestPoint[0] = closestPoint[1] = closestPoint[2] = 0.0;
+  awnorm[0] = awnorm[1] = awnorm[2] = 0.0;
+  *cell_out = -1;
+  *kind_out = -1;
+  if (m->nt == 0)
+    return ret;
+  double p[3], vlen2;
+  int64_t cellId;
+  if (use_grid)
+    orc_find_closest_grid(m, x, p, &cellId, &vlen2);
+  else
+    orc_find_closest_brute(m, x, p, &cellId, &vlen2);
+  if (cellId == -1)
+    return ret;
+  *cell_out = cellId;
+  ret = sqrt(vlen2);
+  for (int i = 0; i < 3; i++)
+    g[i] = (p[i] - x[i]) / (ret == 0. ? 1. : ret);
+
+  double dist2, w[3];
+  eval_cell(m, cellId, p, closestPoint, &dist2, w); /* :388 — evaluated at p, not at x */
+  *kind_out = pseudo_normal(m, cellId, w, awnorm);
   if (ret == 0)
     for (int i = 0; i < 3; i++)
       g[i] = awnorm[i];
   ret *= (dot3(g, awnorm) < 0.) ? 1. : -1.;
   return ret;
+}
+
+/* ---------------------- vtkImplicitPolyDataIntersection::IntersectWithLine
+ * (ICP/vtkImplicitPolyDataIntersection.cxx:110-337).  The first intersection of the segment
+ * p1 -> p2 with the mesh, as vtkCellLocator::IntersectWithLine with tolerance 1e-12 finds it
+ * (:148), restated as: over all triangles, vtkTriangle::IntersectWithLine (plane through
+ * point 1 with the unit normal of vtkTriangle::ComputeNormal, vtkPlane::IntersectWithLine
+ * with its 1e-6 parallelism test, then EvaluatePosition at the plane point: a hit when
+ * inside, or when within the tolerance of the triangle), smallest parameter t first, equal
+ * t to the smallest cell id.  Degenerate triangles (EvaluatePosition -1) never hit.
+ * Outputs as the reference leaves them: ret = NoValue (the bounds' diagonal), g = (0,0,1),
+ * closestPoint = 0 without a hit; with one, closestPoint = EvaluatePosition's point at the
+ * hit, g = the pseudo-normal there, and ret = |p2 - p1| t with the sign the code gives it
+ * (:324: g has just been set to awnorm, so dot(g, awnorm) >= 0 and ret is negated).
+ * x: the plane point itself (the reference keeps it in a local).  Returns 1 on a hit. */
+#define ORC_PLANE_TOL 1.0e-06 /* VTK_PLANE_TOL */
+static int tri_intersect_line(const double p1[3], const double p2[3], const double P0[3],
+  const double P1[3], const double P2[3], double tol, double* t, double x[3])
+{
+  const double *pt1 = P1, *pt2 = P2, *pt3 = P0;
+  double n[3];
+  {
+    /* vtkTriangle::ComputeNormal(pt1, pt2, pt3, n): direction, then unit length */
+    double ax = pt3[0] - pt2[0], ay = pt3[1] - pt2[1], az = pt3[2] - pt2[2];
+    double bx = pt1[0] - pt2[0], by = pt1[1] - pt2[1], bz = pt1[2] - pt2[2];
+    n[0] = ay * bz - az * by;
+    n[1] = az * bx - ax * bz;
+    n[2] = ax * by - ay * bx;
+    double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (len != 0.0)
+    {
+      n[0] /= len;
+      n[1] /= len;
+      n[2] /= len;
+    }
+  }
+  if (n[0] == 0.0 && n[1] == 0.0 && n[2] == 0.0)
+    return 0;
+  /* vtkPlane::IntersectWithLine(p1, p2, n, pt1, t, x) */
+  double p21[3] = { p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2] };
+  double num = dot3(n, pt1) - (n[0] * p1[0] + n[1] * p1[1] + n[2] * p1[2]);
+  double den = n[0] * p21[0] + n[1] * p21[1] + n[2] * p21[2];
+  double fabsden = den < 0.0 ? -den : den;
+  double fabstol = num < 0.0 ? -num * ORC_PLANE_TOL : num * ORC_PLANE_TOL;
+  if (fabsden <= fabstol)
+    return 0;
+  *t = num / den;
+  x[0] = p1[0] + (*t) * p21[0];
+  x[1] = p1[1] + (*t) * p21[1];
+  x[2] = p1[2] + (*t) * p21[2];
+  if (!(*t >= 0.0 && *t <= 1.0))
+    return 0;
+  double cp[3], d2, w[3];
+  int inside = orc_tri_eval(x, P0, P1, P2, cp, &d2, w);
+  if (inside < 0)
+    return 0;
+  if (d2 <= tol * tol)
+    return 1;
+  return inside;
+}
+
+int orc_intersect_line(const orc_mesh* m, const double p1[3], const double p2[3], double* ret,
+  double closestPoint[3], double g[3], double x_out[3], int64_t* cell_out, int* kind_out)
+{
+  *ret = sqrt((m->bmax[0] - m->bmin[0]) * (m->bmax[0] - m->bmin[0]) +
+    (m->bmax[1] - m->bmin[1]) * (m->bmax[1] - m->bmin[1]) +
+    (m->bmax[2] - m->bmin[2]) * (m->bmax[2] - m->bmin[2])); /* NoValue = GetLength() */
+  g[0] = 0.0, g[1] = 0.0, g[2] = 1.0;
+  closestPoint[0] = closestPoint[1] = closestPoint[2] = 0.0;
+  x_out[0] = x_out[1] = x_out[2] = 0.0;
+  *cell_out = -1;
+  *kind_out = -1;
+  double tbest = INFINITY, xb[3] = { 0.0, 0.0, 0.0 };
+  int64_t cbest = -1;
+  for (int64_t c = 0; c < m->nt; c++)
+  {
+    double a[3], b[3], d[3], t, x[3];
+    vtx(m, m->tri[3 * c], a);
+    vtx(m, m->tri[3 * c + 1], b);
+    vtx(m, m->tri[3 * c + 2], d);
+    if (!tri_intersect_line(p1, p2, a, b, d, ORC_TOL, &t, x))
+      continue;
+    if (t < tbest) /* ascending cell id: the first of equal t stays */
+    {
+      tbest = t;
+      cbest = c;
+      xb[0] = x[0], xb[1] = x[1], xb[2] = x[2];
+    }
+  }
+  if (cbest < 0)
+    return 0;
+  *ret = sqrt(dist2pts(p1, p2)) * tbest; /* :155 */
+  *cell_out = cbest;
+  x_out[0] = xb[0], x_out[1] = xb[1], x_out[2] = xb[2];
+  double dist2, w[3], awnorm[3] = { 0.0, 0.0, 0.0 };
+  eval_cell(m, cbest, xb, closestPoint, &dist2, w); /* :169 */
+  *kind_out = pseudo_normal(m, cbest, w, awnorm);
+  for (int i = 0; i < 3; i++)
+    g[i] = awnorm[i]; /* :317-320 */
+  *ret *= (dot3(g, awnorm) < 0.) ? 1. : -1.; /* :324 */
+  return 1;
+}
+
+/* n segments at once (thread-parallel); arrays of 3n doubles, hit / cell / kind per segment */
+void orc_intersect_lines(const orc_mesh* m, const double* p1, const double* p2, int64_t n,
+  int nthreads, int32_t* hit, double* ret, double* closest, double* g, double* x, int32_t* cell,
+  int32_t* kind)
+{
+#ifdef _OPENMP
+  if (nthreads < 1)
+    nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
+#endif
+  for (int64_t i = 0; i < n; i++)
+  {
+    int64_t c;
+    int k;
+    hit[i] = orc_intersect_line(m, p1 + 3 * i, p2 + 3 * i, &ret[i], closest + 3 * i, g + 3 * i,
+      x + 3 * i, &c, &k);
+    cell[i] = (int32_t)c;
+    kind[i] = k;
+  }
 }
 
 /* ------------------------------- vtkPolyDataCorrespondenceFilter functors

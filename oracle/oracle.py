@@ -51,6 +51,9 @@ def _load():
     lib.orc_correspond_f64.argtypes = [
         C.c_void_p, C.c_void_p, C.c_int64, _f64p, C.c_int64, C.c_double, C.c_int, C.c_int,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_intersect_lines.restype = None
+    lib.orc_intersect_lines.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int64, C.c_int, _i32p, _f64p,
+                                        _f64p, _f64p, _f64p, _i32p, _i32p]
     lib.orc_solve.restype = C.c_int
     lib.orc_solve.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p, _f64p]
@@ -124,6 +127,20 @@ class Mesh:
         k = np.zeros(1, np.int32)
         sd = lib().orc_closest_point_and_normal(self.h, x, int(grid), n, cp, c, k)
         return sd, n, cp, int(c[0]), int(k[0])
+
+    def intersect_lines(self, p1, p2, threads=None):
+        """vtkImplicitPolyDataIntersection::IntersectWithLine restated, for n segments."""
+        p1 = np.ascontiguousarray(p1, np.float64).reshape(-1, 3)
+        p2 = np.ascontiguousarray(p2, np.float64).reshape(-1, 3)
+        n = len(p1)
+        out = dict(hit=np.zeros(n, np.int32), ret=np.zeros(n), closest=np.zeros((n, 3)),
+                   normal=np.zeros((n, 3)), point=np.zeros((n, 3)), cell=np.zeros(n, np.int32),
+                   kind=np.zeros(n, np.int32))
+        lib().orc_intersect_lines(self.h, p1.reshape(-1), p2.reshape(-1), n,
+                                  int(threads or num_threads()), out["hit"], out["ret"],
+                                  out["closest"].reshape(-1), out["normal"].reshape(-1),
+                                  out["point"].reshape(-1), out["cell"], out["kind"])
+        return out
 
     def correspond(self, src, T=None, step=1, max_dist=10.0, src_normals=None, min_dot=0.0,
                    grid=True, threads=None, rotate_normals=False):

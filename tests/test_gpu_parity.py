@@ -1225,6 +1225,77 @@ def test_sharded_loop_with_an_empty_shard(icpx, synth, landmarks):
         assert it >= 1 and st in (icpx.RUN_MAX_ITERATIONS, icpx.RUN_CONVERGED)
 
 
+def test_line_intersection_matches_bruteforce(icpx, synth, oracle, small):
+    """icpx_intersect_lines against the oracle's all-triangles restatement of
+    vtkImplicitPolyDataIntersection::IntersectWithLine: hit flags, cells, kinds and every
+    double bit for bit (the device runs the same operations in the same order; only the
+    vertex normals go through acos and may differ in the last place).  Random chords of a
+    closed surface, segments that stop short, rays through vertices and edge midpoints,
+    grazing segments; then the unit cube, where edges and corners are hit exactly."""
+    c, mesh = small
+    xyz, tri = c["target_xyz"], c["target_tri"]
+    n = 6000
+    lo, hi = xyz.min(0).astype(np.float64), xyz.max(0).astype(np.float64)
+    ctr, half = 0.5 * (lo + hi), 0.75 * (hi - lo)
+    a = np.stack([synth.u01(5, 10 + k, n) for k in range(3)], -1) * 2 * half + (ctr - half)
+    b = np.stack([synth.u01(5, 20 + k, n) for k in range(3)], -1) * 2 * half + (ctr - half)
+    b[:500] = a[:500] + 0.02 * (b[:500] - a[:500])          # short ones: mostly no hit
+    nrm = synth.vertex_normals(xyz, tri).astype(np.float64)
+    v = xyz[:600].astype(np.float64)
+    a[1000:1600], b[1000:1600] = v + 0.3 * nrm[:600], v - 0.05 * nrm[:600]   # through vertices
+    mid = 0.5 * (xyz[tri[:600, 0]].astype(np.float64) + xyz[tri[:600, 1]])
+    fn = synth.face_normals(xyz, tri[:600])
+    a[2000:2600], b[2000:2600] = mid + 0.2 * fn, mid - 0.02 * fn             # through edges
+    e = xyz[tri[:300, 1]].astype(np.float64) - xyz[tri[:300, 0]]
+    cen = xyz[tri[:300]].astype(np.float64).mean(1)
+    a[3000:3300], b[3000:3300] = cen - 3 * e + 1e-9 * fn[:300], cen + 3 * e  # grazing a face
+    ctx = icpx.Context(0)
+    ctx.set_target(xyz, tri)
+    got = ctx.intersect_lines(a, b)
+    ref = mesh.intersect_lines(a, b)
+    assert 0.3 < ref["hit"].mean() < 0.95
+    for k in ("hit", "cell", "kind", "ret", "point", "closest"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.abs(got["normal"] - ref["normal"]).max() <= 1e-14
+    face = ref["kind"] == 0
+    assert np.array_equal(got["normal"][face], ref["normal"][face])
+    # every reported hit lies on the segment and on its triangle
+    h = ref["hit"] == 1
+    t = -got["ret"][h] / np.linalg.norm(b[h] - a[h], axis=1)
+    assert np.all((t >= 0) & (t <= 1))
+    assert np.abs(a[h] + t[:, None] * (b[h] - a[h]) - got["point"][h]).max() < 1e-12
+    # the cube: exact edge and corner hits, a miss, the reference's defaults
+    cv = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1],
+                   [0, 1, 1]], np.float32)
+    ct = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [2, 3, 7],
+                   [2, 7, 6], [1, 2, 6], [1, 6, 5], [0, 4, 7], [0, 7, 3]], np.int32)
+    g = np.stack(np.meshgrid(np.linspace(0, 1, 9), np.linspace(0, 1, 9)), -1).reshape(-1, 2)
+    p1 = np.concatenate([g, np.full((len(g), 1), 3.0)], 1)
+    p2 = np.concatenate([g, np.full((len(g), 1), -3.0)], 1)
+    p1 = np.concatenate([p1, [[5, 5, 5]]])
+    p2 = np.concatenate([p2, [[6, 6, 6]]])
+    cube = icpx.Context(0)
+    cube.set_target(cv, ct)
+    got = cube.intersect_lines(p1, p2)
+    ref = oracle.Mesh(cv, ct).intersect_lines(p1, p2)
+    for k in ("hit", "cell", "kind", "ret", "point", "closest"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.abs(got["normal"] - ref["normal"]).max() <= 1e-15
+    assert {0, 1, 2} <= set(ref["kind"].tolist())
+    assert got["hit"][-1] == 0 and got["ret"][-1] == np.sqrt(3.0)
+    assert got["normal"][-1].tolist() == [0, 0, 1] and got["cell"][-1] == -1
+    # the class mirror
+    from iterativeclosestpoint_amd import vtkImplicitPolyDataIntersection, vtkPolyData
+    f = vtkImplicitPolyDataIntersection.New()
+    assert f.IntersectWithLine([0.5, 0.5, 3], [0.5, 0.5, -3])[0] == 0   # no input: error, defaults
+    f.SetInput(vtkPolyData(cv, ct))
+    found, ret, cp, gn, typ = f.IntersectWithLine([0.25, 0.5, 3], [0.25, 0.5, -3])
+    assert found == 1 and ret == -2.0 and cp.tolist() == [0.25, 0.5, 1.0] and typ == 1
+    assert f.NoValue == np.sqrt(3.0)
+    with pytest.raises(icpx.IcpxError):
+        icpx.Context(0).intersect_lines(p1, p2)                          # no target set
+
+
 def test_abi_rejects_bad_input(icpx):
     ctx = icpx.Context(0)
     v = np.zeros((3, 3), np.float32)

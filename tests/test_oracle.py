@@ -149,3 +149,38 @@ def test_generators_are_reproducible():
     u = synth.u01(7, 3, 1000)
     assert np.array_equal(u, synth.u01(7, 3, 1000)) and 0 <= u.min() and u.max() < 1
     assert np.array_equal(synth.u01(7, 3, 10, start=5), u[5:15])
+
+
+def test_line_intersection_known_answers(oracle):
+    """vtkImplicitPolyDataIntersection::IntersectWithLine restated, on the unit cube: hits on a
+    face interior, on the diagonal edge of a face (two coplanar faces: their common normal),
+    on a corner (three faces at right angles: the normalised (1,1,1)), a miss, and a segment
+    that starts inside; the returned value carries the sign the reference's line :324 gives
+    it (always negated), NoValue / NoGradient / zero point without a hit."""
+    v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1],
+                  [0, 1, 1]], np.float32)
+    t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [2, 3, 7],
+                  [2, 7, 6], [1, 2, 6], [1, 6, 5], [0, 4, 7], [0, 7, 3]], np.int32)
+    m = oracle.Mesh(v, t)
+    p1 = np.array([[0.25, 0.5, 3.0], [0.5, 0.5, 3.0], [1, 1, 3.0], [5, 5, 5], [0.3, 0.2, 0.5],
+                   [3.0, 0.25, 0.75]])
+    p2 = np.array([[0.25, 0.5, -3.0], [0.5, 0.5, -3.0], [1, 1, -3.0], [6, 6, 6], [0.3, 0.2, 2.0],
+                   [-3.0, 0.25, 0.75]])
+    r = m.intersect_lines(p1, p2)
+    s3 = 1 / np.sqrt(3)
+    assert r["hit"].tolist() == [1, 1, 1, 0, 1, 1]
+    assert np.allclose(r["ret"], [-2, -2, -2, np.sqrt(3), -0.5, -2], atol=1e-15)
+    assert r["kind"].tolist() == [0, 1, 2, -1, 0, 0]
+    assert r["cell"].tolist() == [3, 2, 2, -1, 2, 9]       # ties on the edge / corner: lowest id
+    assert np.allclose(r["point"], [[0.25, 0.5, 1], [0.5, 0.5, 1], [1, 1, 1], [0, 0, 0],
+                                    [0.3, 0.2, 1], [1, 0.25, 0.75]], atol=1e-15)
+    assert np.allclose(r["closest"], r["point"], atol=1e-15)
+    assert np.allclose(r["normal"], [[0, 0, 1], [0, 0, 1], [s3, s3, s3], [0, 0, 1], [0, 0, 1],
+                                     [1, 0, 0]], atol=1e-15)
+    # a segment that stops short of the surface, one parallel to a face inside its plane
+    r = m.intersect_lines(np.array([[0.5, 0.5, 3.0], [-1.0, 0.5, 1.0]]),
+                          np.array([[0.5, 0.5, 1.5], [2.0, 0.5, 1.0]]))
+    assert r["hit"][0] == 0
+    # (in the plane of the top face: parallel to it, vtkPlane::IntersectWithLine says no; the
+    # side faces x = 0 and x = 1 are crossed at their upper edge)
+    assert r["hit"][1] == 1 and np.allclose(r["point"][1], [0, 0.5, 1]) and r["kind"][1] == 1
