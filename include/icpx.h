@@ -80,9 +80,14 @@ extern "C"
 
   /* Per-point normals of a triangle mesh, computed on the device: the normalised sum of the
    * unit normals of the faces at each point (zero for a point without faces).  Replaces the
-   * filter's own vtkPolyDataNormals with splitting off
+   * filter's own vtkPolyDataNormals with splitting off and consistency on
    * (ICP/vtkPolyDataCorrespondenceFilter.cxx:356-359, run at :457-464), whose output the
    * symmetric metric takes as source normals; pass the result to icpx_set_source.
+   * Consistency: before the normals are made, every edge-connected piece of the mesh takes
+   * the winding of its lowest-numbered cell (cells that run along a shared edge in the same
+   * direction as their neighbour are reversed), which is what VTK's walk from the lowest
+   * unvisited cell yields for orientable pieces; edges shared by more than two cells are not
+   * walked across.
    * normals_out: 3 * nv floats.  The context only supplies the device and the stream. */
   int icpx_point_normals(icpx_ctx* ctx, const float* xyz, int64_t nv, const int32_t* tri,
     int64_t nt, float* normals_out);

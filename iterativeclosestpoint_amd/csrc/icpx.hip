@@ -303,6 +303,7 @@ struct icpx_ctx
   float scene_max = 0.f;
   int exhaustive = 0;
   double build_seconds = 0.0;
+  int64_t last_flips = 0; // cells the last icpx_point_normals reversed for consistent winding
 
   // source
   int64_t np = 0;
@@ -813,9 +814,10 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
   }
   else if (what == 4)
   {
-    int64_t v[9] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
-      c->nbr_total, c->certify_passes, c->split_passes, c->split_wave, c->split_pool };
-    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 9));
+    int64_t v[10] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
+      c->nbr_total, c->certify_passes, c->split_passes, c->split_wave, c->split_pool,
+      c->last_flips };
+    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 10));
     return ICPX_OK;
   }
   else if (what == 3 && c->d_ovf_best)
@@ -1201,7 +1203,7 @@ extern "C" int icpx_point_normals(icpx_ctx* c, const float* xyz, int64_t nv, con
   if (!rc)
     rc = dev_alloc(&voff, nv + 1);
   if (!rc)
-    rc = dev_alloc(&cursor, nv + 1);
+    rc = dev_alloc(&cursor, std::max<int64_t>(nv + 1, 4)); // (also three flag words later on)
   if (!rc)
     rc = dev_alloc(&sscr, scan_scratch_words(nv + 1));
   if (rc)
@@ -1218,12 +1220,60 @@ extern "C" int icpx_point_normals(icpx_ctx* c, const float* xyz, int64_t nv, con
     e = hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (nv + 1), st);
   if (e == hipSuccess)
   {
-    // the same face normals and links as the target's tables are made from
-    k_face_normals<<<nblk(nt, 256), 256, 0, st>>>(d_xyz, d_tri, nullptr, nt, fn64, fn32);
+    // the same links as the target's tables are made from
     k_valence<<<nblk(3 * nt, 256), 256, 0, st>>>(d_tri, 3 * nt, voff);
     exclusive_scan(voff, voff, nv + 1, sscr, st);
     k_fill_links<<<nblk(3 * nt, 256), 256, 0, st>>>(d_tri, 3 * nt, voff, cursor, vcell);
     k_sort_links<<<nblk(nv, 256), 256, 0, st>>>(voff, nv, vcell);
+    e = hipGetLastError();
+  }
+  // ConsistencyOn: cells wound against their piece's lowest cell are reversed first
+  c->last_flips = 0;
+  if (e == hipSuccess)
+  {
+    // (fn64 is not needed yet: its memory holds the neighbour table and the labels meanwhile)
+    int32_t* nbr = reinterpret_cast<int32_t*>(fn64);          // 3 nt int32
+    uint32_t* lab = reinterpret_cast<uint32_t*>(fn64) + 3 * nt; // nt uint32 (fn64 has 6 nt words)
+    uint32_t* flags = cursor;                                   // [0] inconsistent edges, [1] changed, [2] flipped
+    uint32_t h_flags[3] = { 0, 0, 0 };
+    e = hipMemsetAsync(flags, 0, 3 * sizeof(uint32_t), st);
+    if (e == hipSuccess)
+    {
+      k_edge_neighbours<<<nblk(3 * nt, 256), 256, 0, st>>>(d_tri, voff, vcell, nt, nbr, flags);
+      e = hipMemcpyAsync(h_flags, flags, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(st);
+    if (e == hipSuccess && h_flags[0] != 0)
+    {
+      k_orient_init<<<nblk(nt, 256), 256, 0, st>>>(nt, lab);
+      // the smallest cell id of a piece reaches its far end after as many sweeps as the
+      // piece is cells across; look every few dozen sweeps whether anything still moves
+      for (int64_t round = 0; e == hipSuccess && round <= nt / 32 + 1; round++)
+      {
+        e = hipMemsetAsync(flags + 1, 0, sizeof(uint32_t), st);
+        for (int k = 0; k < 32 && e == hipSuccess; k++)
+          k_orient_sweep<<<nblk(nt, 256), 256, 0, st>>>(nbr, nt, lab, flags + 1);
+        if (e == hipSuccess)
+          e = hipMemcpyAsync(h_flags + 1, flags + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+          e = hipStreamSynchronize(st);
+        if (h_flags[1] == 0)
+          break;
+      }
+      if (e == hipSuccess)
+      {
+        k_orient_apply<<<nblk(nt, 256), 256, 0, st>>>(lab, nt, d_tri, flags + 2);
+        e = hipMemcpyAsync(h_flags + 2, flags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+      }
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+      c->last_flips = h_flags[2];
+    }
+  }
+  if (e == hipSuccess)
+  {
+    k_face_normals<<<nblk(nt, 256), 256, 0, st>>>(d_xyz, d_tri, nullptr, nt, fn64, fn32);
     k_point_normals<<<nblk(nv, 256), 256, 0, st>>>(voff, vcell, fn64, nv, d_pn);
     e = hipGetLastError();
   }

@@ -86,6 +86,106 @@ __global__ void k_sort_links(
   }
 }
 
+// ---- consistent winding (vtkPolyDataNormals with ConsistencyOn, which the filter's own
+// normals generator runs with: ICP/vtkPolyDataCorrespondenceFilter.cxx:358).  VTK walks the
+// mesh from the lowest unvisited cell across shared edges and reverses every neighbour that
+// runs along the shared edge in the same direction; the outcome for a mesh of orientable
+// pieces is that each edge-connected piece takes the orientation of its lowest cell.  Here:
+// the neighbour across every manifold edge (exactly one other cell) with the relation
+// "same direction = must differ in flip"; then the smallest cell id of the piece is spread
+// over it together with the flip parity relative to that cell.  Edges with more than two
+// cells are not walked across (VTK's walk over them depends on its queue order).
+//
+// nbr[3 c + e]: (neighbour << 1) | relation across edge e (points e, e+1 of cell c), or -1.
+__global__ void k_edge_neighbours(const int32_t* __restrict__ tri, const uint32_t* __restrict__ voff,
+  const int32_t* __restrict__ vcell, int64_t nt, int32_t* __restrict__ nbr,
+  uint32_t* __restrict__ n_inconsistent)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * nt)
+    return;
+  const int64_t c = i / 3;
+  const int e = (int)(i % 3);
+  const int32_t a = tri[3 * c + e], b = tri[3 * c + (e + 1) % 3];
+  int32_t found = -1, prev = -1;
+  int count = 0, rel = 0;
+  if (a != b)
+    for (uint32_t q = voff[a]; q < voff[a + 1]; q++)
+    {
+      const int32_t o = vcell[q];
+      if (o == prev)
+        continue;
+      prev = o;
+      if (o == (int32_t)c)
+        continue;
+      const int32_t t0 = tri[3 * (int64_t)o], t1 = tri[3 * (int64_t)o + 1], t2 = tri[3 * (int64_t)o + 2];
+      if (t0 != b && t1 != b && t2 != b)
+        continue;
+      count++;
+      found = o;
+      // consistent when the neighbour runs b -> a; the point after its first b is what VTK
+      // looks at (vtkPolyDataNormals::TraverseAndOrder)
+      const int l = (t0 == b) ? 0 : (t1 == b) ? 1 : 2;
+      const int32_t next = (l == 0) ? t1 : (l == 1) ? t2 : t0;
+      rel = (next != a) ? 1 : 0;
+    }
+  const bool manifold = count == 1;
+  nbr[i] = manifold ? ((found << 1) | rel) : -1;
+  if (manifold && rel)
+    atomicAdd(n_inconsistent, 1u);
+}
+
+__global__ void k_orient_init(int64_t nt, uint32_t* __restrict__ lab)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nt)
+    lab[c] = (uint32_t)c << 1; // (piece's lowest cell so far << 1) | flip relative to it
+}
+
+// One sweep: every cell takes the smallest label among its neighbours', with the parity the
+// relation across the edge gives.  Labels only ever decrease, so sweeps may overlap freely.
+__global__ void k_orient_sweep(const int32_t* __restrict__ nbr, int64_t nt,
+  uint32_t* __restrict__ lab, uint32_t* __restrict__ changed)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nt)
+    return;
+  uint32_t best = lab[c];
+  bool ch = false;
+#pragma unroll
+  for (int e = 0; e < 3; e++)
+  {
+    const int32_t nb = nbr[3 * c + e];
+    if (nb < 0)
+      continue;
+    const uint32_t lu = *reinterpret_cast<volatile uint32_t*>(&lab[nb >> 1]);
+    const uint32_t cand = lu ^ (uint32_t)(nb & 1);
+    if ((cand >> 1) < (best >> 1))
+    {
+      best = cand;
+      ch = true;
+    }
+  }
+  if (ch)
+  {
+    lab[c] = best;
+    *changed = 1u;
+  }
+}
+
+// vtkPolyData::ReverseCell on the cells found flipped: (p0, p1, p2) -> (p2, p1, p0).
+__global__ void k_orient_apply(const uint32_t* __restrict__ lab, int64_t nt, int32_t* __restrict__ tri,
+  uint32_t* __restrict__ n_flipped)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nt || !(lab[c] & 1u))
+    return;
+  const int32_t t0 = tri[3 * c];
+  tri[3 * c] = tri[3 * c + 2];
+  tri[3 * c + 2] = t0;
+  atomicAdd(n_flipped, 1u);
+}
+
 // Point normals of a source mesh as the filter's own vtkPolyDataNormals makes them with
 // splitting off (ICP/vtkPolyDataCorrespondenceFilter.cxx:356-359,457-464): the normalised sum
 // of the unit normals of the faces at the point, one term per corner, in link order (fixed,

@@ -181,11 +181,12 @@ class Context:
 
     def debug_stats(self):
         """{shortcut passes, tree-only passes, neighbour-list builds, list radius}."""
-        v = np.zeros(9, np.int64)
-        _chk(load().icpx_debug_dump(self._h, 4, _p(v), 9))
+        v = np.zeros(10, np.int64)
+        _chk(load().icpx_debug_dump(self._h, 4, _p(v), 10))
         return dict(local_passes=int(v[0]), tree_passes=int(v[1]), nbr_builds=int(v[2]),
                     nbr_eps=float(v[3]) * 1e-9, nbr_total=int(v[4]), certify_passes=int(v[5]),
-                    split_passes=int(v[6]), split_wave=int(v[7]), split_pool=int(v[8]))
+                    split_passes=int(v[6]), split_wave=int(v[7]), split_pool=int(v[8]),
+                    winding_flips=int(v[9]))
 
     def debug_counters(self):
         """Counters of the last lane-per-query pass: {ties, overflows, pool position, fallbacks}."""
@@ -272,8 +273,9 @@ class Context:
 
     def point_normals(self, xyz, tri):
         """Per-point normals of a triangle mesh (normalised sum of the unit normals of the faces
-        at each point), computed on the device: what the filter's own vtkPolyDataNormals
-        yields with splitting off (ICP/vtkPolyDataCorrespondenceFilter.cxx:356-359,457-464)."""
+        at each point, after cells wound against their piece's lowest cell have been reversed),
+        computed on the device: what the filter's own vtkPolyDataNormals yields with splitting
+        off and consistency on (ICP/vtkPolyDataCorrespondenceFilter.cxx:356-359,457-464)."""
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
         tri = np.ascontiguousarray(tri, np.int32).reshape(-1, 3)
         out = np.zeros_like(xyz)

@@ -199,12 +199,57 @@ class Mesh:
         return T.reshape(4, 4), it.value, md.value, st, ln.value
 
 
-def point_normals(points, polys):
-    """Point normals as the filter's own vtkPolyDataNormals yields them with splitting off
-    (ICP/vtkPolyDataCorrespondenceFilter.cxx:356-359, run at :457-464): the normalised sum of
-    the unit normals of the incident faces, one term per corner; zero where nothing adds up."""
+def consistent_polys(polys):
+    """vtkPolyDataNormals' ConsistencyOn pass (ICP/vtkPolyDataCorrespondenceFilter.cxx:358),
+    restated from VTK 9.3's vtkPolyDataNormals::TraverseAndOrder: from every cell not yet
+    visited, lowest id first, a wave spreads across shared edges; a neighbour that runs along
+    the shared edge in the same direction is reversed (vtkPolyData::ReverseCell).  Only edges
+    with exactly one other cell are walked across.  Returns (polys, number of reversals)."""
+    polys = np.array(polys, np.int64).reshape(-1, 3)
+    nt = len(polys)
+    cells_of = {}
+    for c in range(nt):
+        for v in set(polys[c].tolist()):
+            cells_of.setdefault(v, []).append(c)
+    visited = np.zeros(nt, bool)
+    flips = 0
+    for seed in range(nt):
+        if visited[seed]:
+            continue
+        visited[seed] = True
+        wave = [seed]
+        while wave:
+            wave2 = []
+            for c in wave:
+                pts = polys[c]
+                for j in range(3):
+                    a, b = int(pts[j]), int(pts[(j + 1) % 3])
+                    if a == b:
+                        continue
+                    nei = [o for o in cells_of[a] if o != c and b in polys[o]]
+                    if len(nei) != 1 or visited[nei[0]]:
+                        continue
+                    o = nei[0]
+                    npts = polys[o].tolist()
+                    pos = npts.index(b)
+                    if npts[(pos + 1) % 3] != a:
+                        polys[o] = polys[o][::-1].copy()
+                        flips += 1
+                    visited[o] = True
+                    wave2.append(o)
+            wave = wave2
+    return polys, flips
+
+
+def point_normals(points, polys, consistency=True):
+    """Point normals as the filter's own vtkPolyDataNormals yields them with splitting off and
+    consistency on (ICP/vtkPolyDataCorrespondenceFilter.cxx:356-359, run at :457-464): the
+    normalised sum of the unit normals of the incident faces, one term per corner; zero where
+    nothing adds up."""
     p = np.asarray(points, np.float32).astype(np.float64)
     polys = np.asarray(polys).reshape(-1, 3)
+    if consistency:
+        polys = consistent_polys(polys)[0]
     a, b, c = p[polys[:, 0]], p[polys[:, 1]], p[polys[:, 2]]
     fn = np.cross(b - a, c - a)
     ln = np.linalg.norm(fn, axis=1, keepdims=True)

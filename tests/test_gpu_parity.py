@@ -981,6 +981,40 @@ def test_point_normals_on_device(icpx, synth, oracle):
         ctx.point_normals(xyz2, np.array([[0, 1, len(xyz2)]], np.int32))
 
 
+def test_point_normals_with_inconsistent_winding(icpx, synth, oracle):
+    """ConsistencyOn of the filter's vtkPolyDataNormals (ICP/vtkPolyDataCorrespondenceFilter.cxx:358):
+    a closed surface with a third of its triangles wound the wrong way, plus a separate
+    patch, against the restated walk of vtkPolyDataNormals::TraverseAndOrder; every piece
+    ends up wound like its lowest cell, so flipping cell 0 as well turns all normals round."""
+    xyz, tri = synth.bumpy_torus(120, 60)
+    n0 = len(xyz)
+    patch_xyz = np.array([[5, 5, 5], [6, 5, 5], [6, 6, 5], [5, 6, 5], [5.5, 5.5, 6]], np.float32)
+    patch_tri = np.array([[0, 1, 4], [2, 1, 4], [2, 3, 4], [0, 3, 4]], np.int32) + n0  # mixed winding
+    xyz2 = np.concatenate([xyz, patch_xyz])
+    clean = np.concatenate([tri, patch_tri])
+    flip = synth.u01(3, 5, len(clean)) < 0.33
+    flip[0] = False
+    flip[len(tri):] = False
+    bad = clean.copy()
+    bad[flip] = bad[flip][:, [1, 0, 2]]                       # swap two points: reversed winding
+    ctx = icpx.Context(0)
+    got = ctx.point_normals(xyz2, bad)
+    assert ctx.debug_stats()["winding_flips"] == int(flip.sum()) + 2   # and two of the patch's four
+    want = oracle.point_normals(xyz2, bad)
+    assert np.abs(got - want).max() <= 1e-6
+    good = ctx.point_normals(xyz2[:n0], tri)                   # the consistent surface by itself
+    assert ctx.debug_stats()["winding_flips"] == 0
+    assert np.abs(got[:n0] - good).max() <= 1e-6
+    outward = synth.vertex_normals(xyz, tri)
+    assert np.abs(good - outward).max() <= 1e-6
+    bad[0] = bad[0][[1, 0, 2]]                                 # now the lowest cell is the odd one
+    inv = ctx.point_normals(xyz2, bad)
+    assert np.abs(inv[:n0] + good).max() <= 1e-6 and np.abs(inv[n0:] - got[n0:]).max() <= 1e-6
+    assert np.abs(inv - oracle.point_normals(xyz2, bad)).max() <= 1e-6
+    # without the consistency pass the flipped faces would cancel their neighbours
+    assert np.abs(oracle.point_normals(xyz2, bad, consistency=False) - inv).max() > 0.5
+
+
 def test_registration_demo_from_a_file(icpx, synth, tmp_path, capsys):
     """The headless registration demo end to end: a PLY file written here, read by the reader
     factory, perturbed as the reference's demo does and registered back with every metric."""
