@@ -9,6 +9,28 @@
 // the signs of the weights, with vtkLine::DistanceToLine's parametrisation.
 // The operation order is kept and the file is compiled with -ffp-contract=off,
 // so every value is the IEEE result a scalar x86-64 build would produce.
+//
+// Where a reader with the VTK 9.3 source tree finds what each routine restates (VTK itself is
+// not part of this repository or of the reference, so files and functions are named, not
+// line numbers):
+//   dist_to_line      Common/DataModel/vtkLine.cxx, vtkLine::DistanceToLine(x, p1, p2, t,
+//                     closestPoint): num = p21.(x - p1), denom = p21.p21, tolerance
+//                     |VTK_TOL * num| with VTK_TOL = 1e-5, p1 when denom < tolerance, then
+//                     t = num / denom clamped to the end points
+//   tri_eval          Common/DataModel/vtkTriangle.cxx, vtkTriangle::EvaluatePosition: points
+//                     taken as pt1 = P1, pt2 = P2, pt3 = P0, vtkTriangle::ComputeNormalDirection,
+//                     vtkPlane::GeneralizedProjectPoint (Common/DataModel/vtkPlane.h),
+//                     the largest |n| component dropped, vtkMath::Determinant2x2 for det and
+//                     the two parametric coordinates, weights (1 - r - s, r, s), the inside
+//                     test 0 <= w <= 1, then the six outside branches in VTK's order (two
+//                     negative weights: corner and two edges; one: one edge)
+//   polygon_normal    Common/DataModel/vtkPolygon.cxx, vtkPolygon::ComputeNormal(vtkPoints*,
+//                     double[3]): cross products accumulated corner by corner, then
+//                     vtkMath::Normalize
+//   tie rule          Common/DataModel/vtkCellLocator.cxx, FindClosestPoint keeps a candidate
+//                     only when its dist2 is smaller than the best so far; which of several
+//                     cells at the same distance it meets first depends on its buckets, so
+//                     the smallest cell id is used here
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -25,6 +25,25 @@
  *   vtkPlane::GeneralizedProjectPoint, vtkPolygon::ComputeNormal,
  *   vtkCellLocator::FindClosestPoint (as: exact minimum over all triangles,
  *   first-smallest wins => smallest cell id on exact ties).
+ *
+ * For an audit against the VTK 9.3 source tree (not available here, so files and
+ * functions are named rather than lines):
+ *   dist_to_line       Common/DataModel/vtkLine.cxx       vtkLine::DistanceToLine (VTK_TOL 1e-5)
+ *   orc_tri_eval       Common/DataModel/vtkTriangle.cxx   vtkTriangle::EvaluatePosition,
+ *                                                         ComputeNormalDirection
+ *                      Common/DataModel/vtkPlane.h        vtkPlane::GeneralizedProjectPoint
+ *                      Common/Core/vtkMath.h              Determinant2x2, Distance2BetweenPoints
+ *   polygon_normal     Common/DataModel/vtkPolygon.cxx    vtkPolygon::ComputeNormal(vtkPoints*, double*)
+ *   tri_intersect_line Common/DataModel/vtkTriangle.cxx   vtkTriangle::IntersectWithLine, ComputeNormal
+ *                      Common/DataModel/vtkPlane.cxx      vtkPlane::IntersectWithLine (VTK_PLANE_TOL 1e-6)
+ *   links              Common/DataModel/vtkPolyData.cxx   BuildLinks, GetCellEdgeNeighbors, GetPointCells
+ *   build_grid / orc_find_closest_grid
+ *                      Common/DataModel/vtkCellLocator.cxx BuildLocator, FindClosestPoint (only
+ *                                                         their shape: a uniform bucket grid
+ *                                                         searched in growing shells)
+ * Checks that share no arithmetic with this file: tests/test_pins.py (answers worked out by
+ * hand, numpy's SVD / solve for the solvers) and, on the GPU, Ericson's closest point on a
+ * triangle against the emitted distances.
  */
 #include <math.h>
 #include <stdint.h>

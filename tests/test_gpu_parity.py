@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch  # noqa: F401  (before libicpx.so is loaded: both bring a HIP runtime, torch's must come first)
 
-from helpers import rel_err, sums_from_rows
+from helpers import hand_cases, rel_err, sums_from_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -862,6 +862,103 @@ def _point_triangle_dist(q, P):
     pt = np.where(((d3 >= 0) & (d4 <= d3))[..., None], b + 0 * p, pt)
     pt = np.where(((d1 <= 0) & (d2 <= 0))[..., None], a + 0 * p, pt)
     return np.sqrt(((p - pt) ** 2).sum(-1))
+
+
+def _closest_on_triangles(q, P):
+    """Closest points and distances from points q (n,3) to their nearest of triangles P
+    (m,3,3), all pairs in float64 by Ericson's region walk (Real-Time Collision Detection,
+    5.1.5): no arithmetic in common with the restated vtkTriangle::EvaluatePosition."""
+    a, b, c = P[None, :, 0], P[None, :, 1], P[None, :, 2]
+    p = q[:, None, :]
+    ab, ac, ap = b - a, c - a, p - a
+    d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
+    bp = p - b
+    d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
+    cp = p - c
+    d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
+    va, vb, vc = d3 * d6 - d5 * d4, d5 * d2 - d1 * d6, d1 * d4 - d3 * d2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        den = va + vb + vc
+        v, w = vb / den, vc / den
+        pt = a + ab * v[..., None] + ac * w[..., None]
+        t_ab = (d1 / (d1 - d3))[..., None]
+        t_ac = (d2 / (d2 - d6))[..., None]
+        t_bc = ((d4 - d3) / ((d4 - d3) + (d5 - d6)))[..., None]
+    pt = np.where(((va <= 0) & (d4 - d3 >= 0) & (d5 - d6 >= 0))[..., None], b + (c - b) * t_bc, pt)
+    pt = np.where(((vb <= 0) & (d2 >= 0) & (d6 <= 0))[..., None], a + ac * t_ac, pt)
+    pt = np.where(((d6 >= 0) & (d5 <= d6))[..., None], c + 0 * p, pt)
+    pt = np.where(((vc <= 0) & (d1 >= 0) & (d3 <= 0))[..., None], a + ab * t_ab, pt)
+    pt = np.where(((d3 >= 0) & (d4 <= d3))[..., None], b + 0 * p, pt)
+    pt = np.where(((d1 <= 0) & (d2 <= 0))[..., None], a + 0 * p, pt)
+    dist = np.sqrt(((p - pt) ** 2).sum(-1))
+    k = np.argmin(dist, axis=1)
+    i = np.arange(len(q))
+    return pt[i, k], dist[i, k]
+
+
+def test_emitted_distances_against_an_independent_routine(icpx, synth):
+    """What the library emits (double-precision rows: distance and closest point) against a
+    textbook closest-point-on-triangle routine over all triangles: the closest point on a
+    triangle is unique, so this pins everything but the choice among tied cells and the last
+    bits.  The Bunny stand-in with queries on, near, far from and exactly on vertices of it; the
+    partial-overlap pair with outliers; a soup of slivers and overlapping triangles."""
+    c1 = synth.config_c1()
+    q1 = queries_around(synth, c1["target_xyz"], c1["target_tri"], 3000, seed=19)
+    c5 = synth.config_c5(nu=96, nv=48, npts=6000)
+    n = 3000
+    ctr = (np.stack([synth.u01(4, 10 + k, n) for k in range(3)], -1) - 0.5) * 2.0
+    size = 0.002 + 0.2 * synth.u01(4, 20, n) ** 4
+    e1 = (np.stack([synth.u01(4, 30 + k, n) for k in range(3)], -1) - 0.5) * size[:, None]
+    e2 = (np.stack([synth.u01(4, 40 + k, n) for k in range(3)], -1) - 0.5) * size[:, None]
+    sl = synth.u01(4, 50, n) < 0.1
+    e2[sl] = e1[sl] * 0.5 + e2[sl] * 1e-4
+    soup = np.ascontiguousarray(np.stack([ctr, ctr + e1, ctr + e2], 1).reshape(-1, 3), np.float32)
+    soup_tri = np.arange(len(soup), dtype=np.int32).reshape(-1, 3)
+    qs = (ctr[:2000] + 0.05 * (np.stack([synth.u01(4, 60 + k, 2000) for k in range(3)], -1) - 0.5)
+          ).astype(np.float32)
+    T = synth.rigid(rx=2.0, ry=-1.0, t=(0.01, 0.0, -0.02))
+    for xyz, tri, q in ((c1["target_xyz"], c1["target_tri"], q1),
+                        (c5["target_xyz"], c5["target_tri"], c5["source_xyz"][::3]),
+                        (soup, soup_tri, qs)):
+        ctx = icpx.Context(0)
+        ctx.set_target(xyz, tri)
+        ctx.set_source(q)
+        rows = ctx.correspond_f64(T, step=1, max_dist=1e30)
+        assert len(rows["cell"]) == len(q)
+        x = q.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+        assert np.abs(rows["origin"] - x).max() <= 1e-15 * max(1.0, float(np.abs(x).max()))
+        P = xyz[tri].astype(np.float64)
+        extent = float(np.abs(P).max())
+        # (degenerate triangles are skipped by the locator; none of these meshes has one)
+        pt, dist = _closest_on_triangles(rows["origin"], P)
+        assert np.abs(rows["dist"] - dist).max() <= 1e-12 * extent
+        assert np.abs(rows["closest"] - pt).max() <= 1e-9 * extent
+        # and the float rows are the roundings of the same numbers
+        rf = ctx.correspond(T, step=1, max_dist=1e30)
+        assert np.array_equal(rf["dist"], rows["dist"])
+        assert np.array_equal(rf["closest"], rows["closest"].astype(np.float32))
+
+
+@pytest.mark.parametrize("case", hand_cases(), ids=lambda c: c[0])
+def test_hand_derived_answers_device(icpx, case):
+    """Answers worked out by hand (an edge between faces at a dihedral that is not a right
+    angle, a vertex whose incident angles differ, a query in every outside region of
+    EvaluatePosition) from the device, float and double rows."""
+    name, xyz, tri, q, want = case
+    ctx = icpx.Context(0)
+    ctx.set_target(xyz, tri)
+    ctx.set_source(q)
+    for width in (0, 1, 64):
+        ctx.set_group_width(width)
+        r64 = ctx.correspond_f64(np.eye(4), step=1, max_dist=10.0)
+        assert np.allclose(r64["closest"], want["closest"], atol=1e-15), name
+        assert np.abs(r64["dist"] - want["dist"]).max() <= 1e-15, name
+        assert r64["cell"].tolist() == list(want["cell"]), name
+        assert np.allclose(r64["normal"], want["normal"], atol=1e-15), name
+        r32 = ctx.correspond(np.eye(4), step=1, max_dist=10.0)
+        assert np.array_equal(r32["closest"], np.asarray(want["closest"], np.float32))
+        assert np.abs(r32["normal"] - np.asarray(want["normal"], np.float32)).max() <= 1e-7
+        assert r32["cell"].tolist() == list(want["cell"])
 
 
 def test_certificate_is_below_the_true_gap(icpx, synth):
