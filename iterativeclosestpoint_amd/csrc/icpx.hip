@@ -1728,6 +1728,8 @@ static int run_search3(icpx_ctx* c)
   a.cert_ok = &c->d_state->cert_ok;
   a.cert_cap2 = &c->d_state->cert_cap2;
   a.widen_max = 0.25f * c->mesh_edge;
+  a.setlist = nullptr;
+  a.setseg = 0;
   a.refill = c->refill_override > 0 ? c->refill_override : (c->hint_valid ? 40 : REFILL3);
   hipStream_t st = c->stream;
   const unsigned grid = nblk(c->nq, 256);
@@ -1800,6 +1802,10 @@ static int run_search3(icpx_ctx* c)
       la.work = c->d_work;
       la.work_count = c->d_counters + 16;
       la.segcap = ca.segcap;
+      a.setlist = c->d_work; // (k_contested weighs the certified sets straight off the list)
+      a.setseg = ca.segcap;
+      la.s.setlist = a.setlist;
+      la.s.setseg = a.setseg;
       // (a multiple of the number of segments; four resident rounds of blocks at most)
       lgrid = (lgrid + CERTIFY_SEGS - 1) / CERTIFY_SEGS * CERTIFY_SEGS;
       const unsigned cap = (unsigned)c->num_cus * 16u / CERTIFY_SEGS * CERTIFY_SEGS;

@@ -497,7 +497,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   }
 
   // (a query that stands on a set certificate has its contenders weighed again)
-  push_certified_sets(certset, q, a.cand, a.tie_list, a.counters, lane, lt);
+  // (a listed pass: the sets that passed the check are weighed straight off the list by
+  // k_contested; one tie-list append per wavefront for them was a third of this kernel)
+  if (!LISTED || !a.setlist)
+    push_certified_sets(certset, q, a.cand, a.tie_list, a.counters, lane, lt);
 
   // The list is taken eight entries at a time: the indices, then their boxes, are in
   // flight together (the loads of one entry depend on each other, those of different

@@ -203,6 +203,11 @@ struct Search3Args
   // most widen_max (a fraction of the mesh's edge length).  Triangles in that margin are
   // screened and counted among "the others" with their true distance.
   float widen_max;
+  // k_certify's list of this pass (CERTIFY_SEGS segments of setseg entries, lengths in
+  // counters[16 + s * CERTIFY_SEG_STRIDE]), or null: k_contested weighs the entries with the
+  // top bit set (queries standing on a set certificate) straight off it
+  const uint32_t* setlist;
+  int64_t setseg;
 };
 
 // the margin a query's search is widened by (see Search3Args::widen_max)
@@ -1401,6 +1406,47 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
     if (j == 0)
       a.hint[q] = s;
   }
+  // the queries that stand on a set certificate, straight off k_certify's list: the members
+  // are in cand[] (-1 ends a set of fewer than RING3)
+  if (!a.setlist)
+    return;
+  for (int seg = 0; seg < CERTIFY_SEGS; seg++)
+  {
+    const uint32_t n = a.counters[16 + seg * CERTIFY_SEG_STRIDE];
+    const uint32_t* const list = a.setlist + (int64_t)seg * a.setseg;
+    for (uint32_t r = block * 32u + (threadIdx.x >> 3); r < n; r += ngroups)
+    {
+      const uint32_t entry = list[r];
+      if (!(entry >> 31))
+        continue; // (a query whose certificate failed: the search kernels' business)
+      const int64_t q = entry & 0x7fffffffu;
+      int32_t s = a.cand[q * RING3 + j];
+      // members up to the first -1
+      const unsigned long long neg = __ballot(s < 0);
+      const int g0 = (threadIdx.x & 63) & ~7;
+      const uint32_t negg = (uint32_t)(neg >> g0) & 0xffu;
+      const int cnt = negg ? (__ffs((int)negg) - 1) : RING3;
+      double d2 = INFINITY;
+      int32_t id = 0x7fffffff;
+      if (j < cnt)
+      {
+        const d3 x = xform(T, a.qpos + 3 * q);
+        d3 P0, P1, P2, cp;
+        double dd, w[3];
+        load_tri(a.tverts, s, P0, P1, P2);
+        if (tri_eval(x, P0, P1, P2, cp, dd, w))
+        {
+          d2 = dd;
+          id = a.tid[s];
+        }
+      }
+      else
+        s = -1;
+      group_argmin<8>(d2, id, s);
+      if (j == 0)
+        a.hint[q] = s;
+    }
+  }
 }
 
 // Both kinds of contested query in one launch: the first `rblocks` blocks resolve the near
@@ -1412,7 +1458,7 @@ __global__ __launch_bounds__(256) void k_contested(Search3Args a, unsigned rbloc
   // be gone after one read)
   if (blockIdx.x < rblocks)
   {
-    if (blockIdx.x * 32u < a.counters[0])
+    if (blockIdx.x * 32u < a.counters[0] || a.setlist)
       resolve_ties_body(a, blockIdx.x, rblocks);
   }
   else
