@@ -267,6 +267,7 @@ struct icpx_ctx
   bool after_cold = false; // the last pass was a cold one
   int since_cold = 0;      // passes since the last cold one
   uint32_t* d_work = nullptr;  // queries whose certificates failed (k_certify's list)
+  unsigned long long* d_setmask = nullptr; // one bit per query: to be weighed again by k_contested
   bool certs_live = false;     // the last pass kept certificates for this one to check
   int64_t certify_min = CERTIFY_MIN; // clouds from this size have their certificates checked by k_certify
   bool pass_certs = false; // the pass being enqueued keeps every query's certificate up to date
@@ -557,6 +558,7 @@ static void free_queries(icpx_ctx* c)
   dev_free(&c->d_ovf_best);
   dev_free(&c->d_fallback);
   dev_free(&c->d_cert);
+  dev_free(&c->d_setmask);
   dev_free(&c->d_work);
   c->q_cap = 0;
   c->q3_cap = 0;
@@ -1696,6 +1698,7 @@ static int run_search3(icpx_ctx* c)
     ALLOC(c->d_ovf_best, c->nq);
     ALLOC(c->d_fallback, c->nq);
     ALLOC(c->d_cert, c->nq);
+    ALLOC(c->d_setmask, (c->nq + 63) / 64 + 1);
     c->q3_cap = c->nq;
   }
   const Bin& b = c->bins[(L == 1) ? 0 : (L == 2) ? 1 : 2];
@@ -1728,8 +1731,7 @@ static int run_search3(icpx_ctx* c)
   a.cert_ok = &c->d_state->cert_ok;
   a.cert_cap2 = &c->d_state->cert_cap2;
   a.widen_max = 0.25f * c->mesh_edge;
-  a.setlist = nullptr;
-  a.setseg = 0;
+  a.setmask = nullptr; // (set below, once the pass's kernels are known)
   a.refill = c->refill_override > 0 ? c->refill_override : (c->hint_valid ? 40 : REFILL3);
   hipStream_t st = c->stream;
   const unsigned grid = nblk(c->nq, 256);
@@ -1751,6 +1753,10 @@ static int run_search3(icpx_ctx* c)
   c->since_cold = c->hint_valid ? c->since_cold + 1 : 0;
   c->pass_certs = c->use_cert && (mode == 1 || (mode == 3 && c->since_cold >= 2));
   a.cert = c->pass_certs ? c->d_cert : nullptr;
+  // a kernel that checks every query's certificate runs in this pass (the shortcut or
+  // k_certify, or the wavefront walk over the whole cloud): it marks the queries that stand
+  // on set certificates for k_contested
+  a.setmask = (a.cert && (use_local || mode == 3)) ? c->d_setmask : nullptr;
   ScopedTimer tm(c, 0, true);
   tm.kind = use_local ? 1 : 0;
   tm.hinted = c->hint_valid ? 1 : 0;
@@ -1797,15 +1803,12 @@ static int run_search3(icpx_ctx* c)
       ca.rounds = (int)std::min<int64_t>(std::max<int64_t>(c->nq / (256 * 2048), 1), CERTIFY_ROUNDS);
       const unsigned cgrid = nblk(c->nq, 256 * ca.rounds);
       ca.segcap = (int64_t)((cgrid + CERTIFY_SEGS - 1) / CERTIFY_SEGS) * 256 * ca.rounds;
+      ca.setmask = c->d_setmask;
       launch_ev(c, false, k_certify, cgrid, 256, st, ca);
       c->certify_passes++;
       la.work = c->d_work;
       la.work_count = c->d_counters + 16;
       la.segcap = ca.segcap;
-      a.setlist = c->d_work; // (k_contested weighs the certified sets straight off the list)
-      a.setseg = ca.segcap;
-      la.s.setlist = a.setlist;
-      la.s.setseg = a.setseg;
       // (a multiple of the number of segments; four resident rounds of blocks at most)
       lgrid = (lgrid + CERTIFY_SEGS - 1) / CERTIFY_SEGS * CERTIFY_SEGS;
       const unsigned cap = (unsigned)c->num_cus * 16u / CERTIFY_SEGS * CERTIFY_SEGS;

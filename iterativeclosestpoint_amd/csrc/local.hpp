@@ -496,11 +496,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     }
   }
 
-  // (a query that stands on a set certificate has its contenders weighed again)
-  // (a listed pass: the sets that passed the check are weighed straight off the list by
-  // k_contested; one tie-list append per wavefront for them was a third of this kernel)
-  if (!LISTED || !a.setlist)
-    push_certified_sets(certset, q, a.cand, a.tie_list, a.counters, lane, lt);
+  // (a query that stands on a set certificate has its contenders weighed again by
+  // k_contested: a whole pass marks the 64 queries of each wavefront in one word; a listed
+  // pass has had that done by k_certify)
+  if (!LISTED && a.setmask)
+  {
+    const unsigned long long ms = __ballot(certset);
+    const int64_t w0 = first + (tid & ~63);
+    if (lane == 0 && w0 < total)
+      a.setmask[w0 >> 6] = ms;
+  }
 
   // The list is taken eight entries at a time: the indices, then their boxes, are in
   // flight together (the loads of one entry depend on each other, those of different
@@ -660,6 +665,7 @@ struct CertifyArgs
   uint32_t* work_count;
   int64_t segcap;
   int rounds; // queries per block / 256 (1 .. CERTIFY_ROUNDS)
+  unsigned long long* setmask; // one bit per query: passed, and stands on a set certificate
 };
 
 constexpr int CERTIFY_ROUNDS = 16;
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
   const bool far_on = cert_on && c.cap2 <= uniform_f64(capv) * (1.0 + 1e-12);
   const int rounds = c.rounds;
   const int64_t first = (int64_t)blockIdx.x * (256 * rounds) + tid;
-  uint32_t todo_bits = 0, set_bits = 0;
+  uint32_t todo_bits = 0;
   for (int k = 0; k < rounds; k++)
   {
     const int64_t q = first + (int64_t)k * 256;
@@ -723,9 +729,13 @@ __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
       }
     }
     const bool todo = active && !certified;
-    todo_bits |= ((todo || certset) ? 1u : 0u) << k;
-    set_bits |= (certset ? 1u : 0u) << k;
-    const unsigned long long mf = __ballot(todo || certset);
+    todo_bits |= (todo ? 1u : 0u) << k;
+    // (the wavefront's 64 consecutive queries: their marks are one word)
+    const unsigned long long ms = __ballot(certset);
+    const int64_t w0 = (int64_t)blockIdx.x * (256 * rounds) + (int64_t)k * 256 + wave * 64;
+    if (lane == 0 && w0 < c.nq)
+      c.setmask[w0 >> 6] = ms;
+    const unsigned long long mf = __ballot(todo);
     if (lane == 0)
       wcount[k * 4 + wave] = (uint32_t)__popcll(mf);
   }
@@ -751,8 +761,7 @@ __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
     const bool listed = (todo_bits >> k) & 1u;
     const unsigned long long mf = __ballot(listed);
     if (listed)
-      work[bbase + wcount[k * 4 + wave] + (uint32_t)__popcll(mf & lt)] =
-        (uint32_t)q | (((set_bits >> k) & 1u) << 31);
+      work[bbase + wcount[k * 4 + wave] + (uint32_t)__popcll(mf & lt)] = (uint32_t)q;
   }
 }
 

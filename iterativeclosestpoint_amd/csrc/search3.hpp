@@ -203,11 +203,12 @@ struct Search3Args
   // most widen_max (a fraction of the mesh's edge length).  Triangles in that margin are
   // screened and counted among "the others" with their true distance.
   float widen_max;
-  // k_certify's list of this pass (CERTIFY_SEGS segments of setseg entries, lengths in
-  // counters[16 + s * CERTIFY_SEG_STRIDE]), or null: k_contested weighs the entries with the
-  // top bit set (queries standing on a set certificate) straight off it
-  const uint32_t* setlist;
-  int64_t setseg;
+  // One bit per query: it stands on a set certificate that passed this pass's check, so its
+  // contenders (cand[]) are to be weighed again by k_contested.  Every kernel that checks
+  // certificates handles 64 consecutive queries per wavefront and stores their 64 bits as
+  // one word, set or not: no counter, no list, nothing to clear.  Null in a pass without
+  // such a kernel.
+  unsigned long long* setmask;
 };
 
 // the margin a query's search is widened by (see Search3Args::widen_max)
@@ -235,32 +236,6 @@ __device__ __forceinline__ float widen_of(const Search3Args& a, const Xf& T, con
 // with counts this many words apart.
 constexpr int CERTIFY_SEGS = 32;
 constexpr int CERTIFY_SEG_STRIDE = 64;
-
-// The queries of a wavefront that stand on a set certificate join the pass's tie list; their
-// contenders are in cand[] already (-1 ends a set of fewer than RING3).
-__device__ __forceinline__ void push_certified_sets(bool isset, int64_t q, const int32_t* cand,
-  uint2* tie_list, uint32_t* counters, int lane, unsigned long long lt)
-{
-  const unsigned long long mt = __ballot(isset);
-  if (!mt)
-    return;
-  const int leader = __ffsll((long long)mt) - 1;
-  uint32_t base = 0;
-  if (lane == leader)
-    base = atomicAdd(&counters[0], (uint32_t)__popcll(mt));
-  base = __shfl(base, leader, 64);
-  if (isset)
-  {
-    const int4 c0 = *reinterpret_cast<const int4*>(cand + q * RING3);
-    const int4 c1 = *reinterpret_cast<const int4*>(cand + q * RING3 + 4);
-    const int32_t m[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
-    int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-      cnt += (cnt == i && m[i] >= 0) ? 1 : 0;
-    tie_list[base + __popcll(mt & lt)] = make_uint2((uint32_t)q, (uint32_t)cnt);
-  }
-}
 
 // fp32 lower bound of the squared distance to a box; never above the true value
 __device__ __forceinline__ float box_lb(float lox, float loy, float loz, float hix, float hiy,
@@ -1013,7 +988,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
           active = !(keep != 0.f);
         }
       }
-      push_certified_sets(isset, q, a.cand, a.tie_list, a.counters, lane, lt);
+    }
+    if (a.setmask && !a.qlist)
+    {
+      // (a whole pass: these are queries base .. base + 63)
+      const unsigned long long ms = __ballot(isset);
+      if (lane == 0)
+        a.setmask[base >> 6] = ms;
     }
     if (__ballot(active) == 0ull)
       continue; // every query of the block went through
@@ -1406,45 +1387,46 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
     if (j == 0)
       a.hint[q] = s;
   }
-  // the queries that stand on a set certificate, straight off k_certify's list: the members
-  // are in cand[] (-1 ends a set of fewer than RING3)
-  if (!a.setlist)
+  // the queries that stand on a set certificate (one bit each in setmask): every lane takes
+  // half a word, 32 consecutive queries, and weighs the members of each marked one itself
+  // (cand[], -1 ends a set of fewer than RING3).  Where a tenth of the cloud stands on sets
+  // every lane has a few to do; where it is a thousand queries, a few lanes do.
+  if (!a.setmask)
     return;
-  for (int seg = 0; seg < CERTIFY_SEGS; seg++)
+  const int64_t halves = (a.nq + 31) / 32;
+  const uint32_t* const half = reinterpret_cast<const uint32_t*>(a.setmask);
+  for (int64_t h = (int64_t)block * 256 + threadIdx.x; h < halves; h += (int64_t)nblocks * 256)
   {
-    const uint32_t n = a.counters[16 + seg * CERTIFY_SEG_STRIDE];
-    const uint32_t* const list = a.setlist + (int64_t)seg * a.setseg;
-    for (uint32_t r = block * 32u + (threadIdx.x >> 3); r < n; r += ngroups)
+    uint32_t bits = half[h];
+    while (bits)
     {
-      const uint32_t entry = list[r];
-      if (!(entry >> 31))
-        continue; // (a query whose certificate failed: the search kernels' business)
-      const int64_t q = entry & 0x7fffffffu;
-      int32_t s = a.cand[q * RING3 + j];
-      // members up to the first -1
-      const unsigned long long neg = __ballot(s < 0);
-      const int g0 = (threadIdx.x & 63) & ~7;
-      const uint32_t negg = (uint32_t)(neg >> g0) & 0xffu;
-      const int cnt = negg ? (__ffs((int)negg) - 1) : RING3;
-      double d2 = INFINITY;
-      int32_t id = 0x7fffffff;
-      if (j < cnt)
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1u;
+      const int64_t q = h * 32 + b;
+      const d3 x = xform(T, a.qpos + 3 * q);
+      const int4 c0 = *reinterpret_cast<const int4*>(a.cand + q * RING3);
+      const int4 c1 = *reinterpret_cast<const int4*>(a.cand + q * RING3 + 4);
+      const int32_t m[RING3] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+      double bd2 = INFINITY;
+      int32_t bid = 0x7fffffff, bs = -1;
+#pragma unroll 1
+      for (int i = 0; i < RING3 && m[i] >= 0; i++)
       {
-        const d3 x = xform(T, a.qpos + 3 * q);
         d3 P0, P1, P2, cp;
         double dd, w[3];
-        load_tri(a.tverts, s, P0, P1, P2);
+        load_tri(a.tverts, m[i], P0, P1, P2);
         if (tri_eval(x, P0, P1, P2, cp, dd, w))
         {
-          d2 = dd;
-          id = a.tid[s];
+          const int32_t id = a.tid[m[i]];
+          if (better(dd, id, bd2, bid))
+          {
+            bd2 = dd;
+            bid = id;
+            bs = m[i];
+          }
         }
       }
-      else
-        s = -1;
-      group_argmin<8>(d2, id, s);
-      if (j == 0)
-        a.hint[q] = s;
+      a.hint[q] = bs;
     }
   }
 }
@@ -1458,7 +1440,7 @@ __global__ __launch_bounds__(256) void k_contested(Search3Args a, unsigned rbloc
   // be gone after one read)
   if (blockIdx.x < rblocks)
   {
-    if (blockIdx.x * 32u < a.counters[0] || a.setlist)
+    if (blockIdx.x * 32u < a.counters[0] || a.setmask)
       resolve_ties_body(a, blockIdx.x, rblocks);
   }
   else
