@@ -1731,6 +1731,7 @@ static int run_search3(icpx_ctx* c)
   a.cert_ok = &c->d_state->cert_ok;
   a.cert_cap2 = &c->d_state->cert_cap2;
   a.widen_max = 0.25f * c->mesh_edge;
+  a.pairs = (c->certify_min >= 0 && c->nq >= c->certify_min) ? 1 : 0;
   a.setmask = nullptr; // (set below, once the pass's kernels are known)
   a.refill = c->refill_override > 0 ? c->refill_override : (c->hint_valid ? 40 : REFILL3);
   hipStream_t st = c->stream;
@@ -1854,6 +1855,7 @@ static int run_search3(icpx_ctx* c)
     wide.cert = a.cert;
     wide.cand = c->d_cand;
     wide.widen = a.cert ? a.widen_max : 0.f;
+    wide.pairs = a.pairs;
     widep = &wide;
   }
   if (L == 1)
@@ -1918,6 +1920,7 @@ static int run_search(icpx_ctx* c)
     a.cert = nullptr;
     a.cand = nullptr;
     a.widen = 0.f;
+    a.pairs = 0;
     ScopedTimer tm(c, 0);
     switch (G)
     {
@@ -2199,6 +2202,7 @@ extern "C" int icpx_accumulate_static(icpx_ctx* c, int metric, const double T[16
   a.cert = nullptr;
   a.cand = nullptr;
   a.widen = 0.f;
+  a.pairs = 0;
   if (G == 64)
     launch_search2<64>(a, nblk(nq, 256 / 64), st);
   else

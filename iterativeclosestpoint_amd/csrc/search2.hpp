@@ -314,6 +314,7 @@ struct Search2Args
   int32_t* cand;   // [nq][RING3] contender sets behind set certificates (or null: no sets)
   float widen;     // margin by which the walk looks beyond its bound, so that a far certificate
                    // is worth something (0 when certificates are not kept)
+  int pairs;       // keep a winner and a rival next to nothing behind as a set of two
 };
 
 template <int G>
@@ -563,7 +564,7 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
         {
           bool pair;
           nearc = make_certificate_pair(1, best, m1, m2, a.cand ? id1 : -1, INFINITY, dbox, tau,
-            eabs, a.cap2, fmaxf(a.widen, 4.f * eabs), pair);
+            eabs, a.cap2, a.pairs ? fmaxf(a.widen, 4.f * eabs) : -INFINITY, pair);
           if (pair && j == 0)
           {
             a.cand[q * RING3 + 0] = ring[g][0];

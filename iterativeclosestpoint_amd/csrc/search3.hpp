@@ -203,6 +203,12 @@ struct Search3Args
   // most widen_max (a fraction of the mesh's edge length).  Triangles in that margin are
   // screened and counted among "the others" with their true distance.
   float widen_max;
+  // Whether a single winner with a rival next to nothing behind may be kept with that rival
+  // as a set of two (make_certificate_pair).  Every set costs k_contested an exact
+  // evaluation per member and pass; searching the rival-ridden queries again instead costs
+  // about 4 ns apiece per pass.  Sets win where those queries are many (a noisy cloud of
+  // millions); for a thousand of them the search is lost in a launch that runs anyway.
+  int pairs;
   // One bit per query: it stands on a set certificate that passed this pass's check, so its
   // contenders (cand[]) are to be weighed again by k_contested.  Every kernel that checks
   // certificates handles 64 consecutive queries per wavefront and stores their 64 bits as
@@ -235,6 +241,9 @@ __device__ __forceinline__ float widen_of(const Search3Args& a, const Xf& T, con
 // The list of queries whose certificates failed (k_certify) is kept in this many segments,
 // with counts this many words apart.
 constexpr int CERTIFY_SEGS = 32;
+// marked queries among a wavefront's 2048 up to which k_contested deals them out to groups
+// of eight lanes (beyond: every lane weighs its own)
+constexpr uint32_t SPARSE_SETS = 16;
 constexpr int CERTIFY_SEG_STRIDE = 64;
 
 // fp32 lower bound of the squared distance to a box; never above the true value
@@ -591,7 +600,7 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
         // more than none)
         bool pair;
         a.cert[q] = make_certificate_pair(cnt, best, sec2, sec3, sec_id, minraw, INFINITY, tau,
-          eabs, a.cap2, fmaxf(widen, 4.f * eabs), pair);
+          eabs, a.cap2, a.pairs ? fmaxf(widen, 4.f * eabs) : -INFINITY, pair);
         if (pair)
         {
           // the set of two, for later passes (this pass's winner is settled: the loser is
@@ -1358,10 +1367,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
 __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned block,
   unsigned nblocks)
 {
+  // (the list's length and the wavefront's first mask words are read side by side, before
+  // the transform: in most passes of a clean cloud most wavefronts find nothing and leave
+  // after this one round of reads)
+  const int64_t halves = (a.nq + 31) / 32;
+  const uint32_t* const half = reinterpret_cast<const uint32_t*>(a.setmask);
+  const int lane = threadIdx.x & 63;
+  const int64_t hfirst = (int64_t)block * 256 + (threadIdx.x & ~63);
+  const uint32_t total = a.counters[0];
+  const uint32_t bits_first = (a.setmask && hfirst + lane < halves) ? half[hfirst + lane] : 0u;
+  if (block * 32u >= total && hfirst + (int64_t)nblocks * 256 >= halves &&
+    __ballot(bits_first != 0u) == 0ull)
+    return;
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
-  const uint32_t total = a.counters[0];
   const int j = threadIdx.x & 7;
   const uint32_t ngroups = nblocks * 32u;
   for (uint32_t r = block * 32u + (threadIdx.x >> 3); r < total; r += ngroups)
@@ -1387,17 +1407,70 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
     if (j == 0)
       a.hint[q] = s;
   }
-  // the queries that stand on a set certificate (one bit each in setmask): every lane takes
-  // half a word, 32 consecutive queries, and weighs the members of each marked one itself
-  // (cand[], -1 ends a set of fewer than RING3).  Where a tenth of the cloud stands on sets
-  // every lane has a few to do; where it is a thousand queries, a few lanes do.
+  // the queries that stand on a set certificate (one bit each in setmask): a wavefront takes
+  // 64 half words, 2048 consecutive queries.  Where many of them are marked (a tenth of a
+  // noisy cloud stands on sets) every lane weighs the members of its own 32 queries' sets
+  // one after the other (cand[], -1 ends a set of fewer than RING3); where few are (a
+  // thousand of a million), they are dealt out to groups of eight lanes, one member per
+  // lane, so that a pass is one exact evaluation long instead of several in a row.
   if (!a.setmask)
     return;
-  const int64_t halves = (a.nq + 31) / 32;
-  const uint32_t* const half = reinterpret_cast<const uint32_t*>(a.setmask);
-  for (int64_t h = (int64_t)block * 256 + threadIdx.x; h < halves; h += (int64_t)nblocks * 256)
+  for (int64_t h0 = hfirst; h0 < halves; h0 += (int64_t)nblocks * 256)
   {
-    uint32_t bits = half[h];
+    const int64_t h = h0 + lane;
+    uint32_t bits = h0 == hfirst ? bits_first : (h < halves ? half[h] : 0u);
+    const uint32_t mine = (uint32_t)__popc(bits);
+    const uint32_t incl = wave_incl_scan(mine, lane);
+    const uint32_t marked = (uint32_t)__shfl((int)incl, 63, 64);
+    if (marked == 0u)
+      continue;
+    if (marked <= SPARSE_SETS)
+    {
+      for (uint32_t r0 = 0; r0 < marked; r0 += 8)
+      {
+        // the r-th marked query of the wavefront's 2048: the first lane whose running count
+        // exceeds r holds it, as the (r - count before that lane)-th set bit of its word
+        int64_t q = -1;
+        for (uint32_t r = r0; r < marked && r < r0 + 8; r++)
+        {
+          const int src = __ffsll((long long)__ballot(incl > r)) - 1;
+          const uint32_t isrc = (uint32_t)__shfl((int)incl, src, 64);
+          const uint32_t msrc = (uint32_t)__shfl((int)mine, src, 64);
+          uint32_t bb = (uint32_t)__shfl((int)bits, src, 64);
+          for (uint32_t k = r - (isrc - msrc); k > 0; k--)
+            bb &= bb - 1u;
+          if ((uint32_t)(lane >> 3) == r - r0)
+            q = (h0 + src) * 32 + (__ffs((int)bb) - 1);
+        }
+        int32_t s = q >= 0 ? a.cand[q * RING3 + j] : -1;
+        // members up to the first -1
+        const unsigned long long neg = __ballot(s < 0);
+        const uint32_t negg = (uint32_t)(neg >> (lane & ~7)) & 0xffu;
+        const int cnt = negg ? (__ffs((int)negg) - 1) : RING3;
+        double d2 = INFINITY;
+        int32_t id = 0x7fffffff;
+        if (j < cnt)
+        {
+          const d3 x = xform(T, a.qpos + 3 * q);
+          d3 P0, P1, P2, cp;
+          double dd, w[3];
+          load_tri(a.tverts, s, P0, P1, P2);
+          if (tri_eval(x, P0, P1, P2, cp, dd, w))
+          {
+            d2 = dd;
+            id = a.tid[s];
+          }
+          else
+            s = -1;
+        }
+        else
+          s = -1;
+        group_argmin<8>(d2, id, s);
+        if (j == 0 && q >= 0)
+          a.hint[q] = s;
+      }
+      continue;
+    }
     while (bits)
     {
       const int b = __ffs((int)bits) - 1;

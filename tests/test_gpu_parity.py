@@ -961,9 +961,12 @@ def test_hand_derived_answers_device(icpx, case):
         assert r32["cell"].tolist() == list(want["cell"])
 
 
-def test_certificate_is_below_the_true_gap(icpx, synth):
+@pytest.mark.parametrize("local", [1, 3])
+def test_certificate_is_below_the_true_gap(icpx, synth, local):
     """The slack a query is given never exceeds what it certifies: the distance of the
-    second nearest triangle less that of the nearest (all pairs, brute force in numpy)."""
+    second nearest triangle less that of the nearest (all pairs, brute force in numpy).
+    local = 3: as for a cloud of millions (certificates checked by their own kernel, and a
+    winner with a rival next to nothing behind kept with it as a set of two)."""
     xyz, tri = synth.bumpy_torus(48, 24)
     pts, f, fn = synth.sample_surface(xyz, tri, 40_000, seed=33)
     off = np.stack([synth.gaussian(8, 90 + 2 * k, len(pts)) for k in range(3)], -1)
@@ -971,6 +974,7 @@ def test_certificate_is_below_the_true_gap(icpx, synth):
     src = (pts.astype(np.float64) + off * scale[:, None]).astype(np.float32)
     ctx = icpx.Context(0)
     ctx.set_group_width(1)
+    ctx.set_local(local)
     ctx.set_target(xyz, tri)
     ctx.set_source(src)
     T = synth.rigid(rz=0.01, t=(1e-4, 0, 0))
