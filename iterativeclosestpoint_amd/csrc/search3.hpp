@@ -885,6 +885,25 @@ __device__ __forceinline__ void tri_bounds_rec(float nx, float ny, float nz, flo
   ub = vhi * vhi * 1.000001f;
 }
 
+// The lower bound of tri_bounds_rec with one square root instead of three, for the walk that
+// takes it of every triangle of every leaf it enters.  v = query - centroid and q2 = |v|^2 as
+// computed in fp32.  Where tri_bounds_rec uses |v| it is bounded from above by the sum of the
+// components' magnitudes (in the allowance of the plane distance, and in the cross term of
+// (|v| (1 - 5e-7) - 2 eabs)^2 >= 0.9999987 q2 - 4 eabs |v|, whose square term is dropped);
+// 0.999998 leaves room for the roundings of the three operations that follow.
+__device__ __forceinline__ float tri_lb_rec(float nx, float ny, float nz, float allow, float R,
+  float vx, float vy, float vz, float q2, float eabs)
+{
+  const float l1 = (fabsf(vx) + fabsf(vy)) + fabsf(vz);
+  const float m = __builtin_fmaf(6.1e-7f, l1, 4.f * eabs + allow);
+  const float pd = fabsf(__builtin_fmaf(nz, vz, __builtin_fmaf(ny, vy, nx * vx)));
+  const float pd_lo = fmaxf(pd - m, 0.f), pd_hi = pd + m;
+  const float w = __builtin_fmaf(-4.00001f * eabs, l1, 0.999998f * q2);
+  const float in2 = fmaxf(__builtin_fmaf(-pd_hi, pd_hi, w), 0.f);
+  const float ld = fmaxf(__builtin_amdgcn_sqrtf(in2) * 0.9999995f - (R + 3.f * eabs), 0.f);
+  return __builtin_fmaf(ld, ld, pd_lo * pd_lo) * 0.999999f;
+}
+
 // The search with one walk per wavefront.  Queries are in Morton order, so the 64 of a
 // wavefront lie within a few triangle widths of each other and their walks visit nearly
 // the same boxes; here the wavefront walks the tree ONCE for all of them.  The node, the
@@ -894,12 +913,13 @@ __device__ __forceinline__ void tri_bounds_rec(float nx, float ny, float nz, flo
 // A box is entered when any lane's bound reaches it.  Two levels are taken per step: the
 // records of both children of a node share a 128-byte line and hold the four
 // grandchildren's boxes, which halves the chain of dependent reads.  Order of descent
-// follows the first interested lane.  At a leaf every lane takes the cheap lower and upper
-// bounds of each triangle (tri_bounds_rec), tightens its bound with the upper one and queues
-// the triangle (per lane, in LDS) if the lower one is within it.  Queued triangles are
-// screened in fp64 when some lane's queue is full and when the walk is over, every lane
-// its own triangle: by then most have dropped out against the tighter bound, and the
-// screen runs with most lanes busy.  Wavefronts draw blocks of 64 queries from
+// follows the first interested lane.  At a leaf every lane takes the cheap lower bound of
+// each triangle (tri_lb_rec) and the centroids' distances as upper bounds, tightens its bound
+// with the latter and queues the triangle (per lane, in LDS) if the former is within it.
+// When some lane's queue is full, and when the walk is over, the queues are weeded (entries
+// the bound has overtaken go unscreened) and every lane screens its most promising entry in
+// fp64: the bound that leaves behind turns most of the others away, and the screen runs with
+// most lanes busy.  Wavefronts draw blocks of 64 queries from
 // counters[2].  Results per query are those of k_search3p: bounds only ever remove
 // triangles that cannot be contenders, and a triangle is a contender by the same per-lane
 // test whatever the order of the walk.
@@ -947,7 +967,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
   cfloat4* nodes4 = (cfloat4*)(uintptr_t)a.nodes;
   cfloat4* tpre4 = (cfloat4*)(uintptr_t)a.tpre;
 #ifdef ICPX_STATS
-  unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0;
+  unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0, st_6 = 0, st_7 = 0;
 #endif
 
   // (the first 64 queries of a wavefront are its own by its number, later ones come off
@@ -1017,9 +1037,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     // ubq: squared centroid distance behind ubf; rpf: square root of prunef, rounded up
     float boundf = FLT_MAX, ubf = FLT_MAX, prunef = FLT_MAX, bboxf = active ? INFINITY : -1.f;
     float ubq = FLT_MAX, rpf = 1.9e19f;
-    float sec2 = INFINITY, minraw = INFINITY, minlin = INFINITY; // for the certificate
+    float sec2 = INFINITY, minraw = INFINITY; // for the certificate
     float widen = 0.f; // margin by which the walk looks farther (widen_of)
-    int cnt = 0, npend = 0, phead = 0; // queue: npend entries from slot phead on, oldest first
+    int cnt = 0, npend = 0; // queue: slots 0 .. npend-1 of this lane's column, in no order
+    int pick = -1;          // after purge(): the slot of the queued triangle with the smallest bound
     int32_t hs_used = -1;
 
     auto retighten = [&]() {
@@ -1042,30 +1063,63 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
       boundf = fminf(fmaxf(__double2float_ru(rw * rw), FLT_MIN), FLT_MAX);
       retighten();
     };
-    auto screen_one = [&]() { // the oldest queued triangle (nearest leaves come first), if
-                              // it is still in the race
-      const int slot = phead & (PENDW - 1);
-      phead++;
-      npend--;
-      const int32_t s = pend_s[slot][lane];
-      const float lbq = __uint_as_float((uint32_t)pend_lb[slot][lane] << 16);
-      if (lbq > prunef)
-        sec2 = fminf(sec2, lbq); // dropped against the tighter bound: at least that far
-      else
+    // The queue is weeded and its most promising entry found: entries whose bound has
+    // fallen behind the lane's (they count for the certificate with that bound) go, the rest
+    // close ranks.  A few cheap instructions per slot, against the few hundred of a screen.
+    auto purge = [&]() {
+      int w = 0;
+      float mlb = INFINITY;
+      pick = -1;
+#pragma nounroll
+      for (int i = 0; i < PENDW; i++)
       {
-        STAT(3, 1);
-        d3 P0, P1, P2;
-        load_tri(a.tverts, s, P0, P1, P2);
-        const double d2 = tri_d2_screen(x, P0, P1, P2);
-        sec2 = note_screened(sec2, d2, best, bound, tau, cnt);
-        if (d2 < best)
-          set_best(d2);
-        if (d2 <= bound)
+        if (__ballot(i < npend) == 0ull)
+          break;
+        if (i < npend)
         {
-          if (cnt < RING3)
-            ring[cnt][lane] = s;
-          cnt++;
+          const int32_t s = pend_s[i][lane];
+          const uint16_t h = pend_lb[i][lane];
+          const float lbq = __uint_as_float((uint32_t)h << 16);
+          if (lbq > prunef)
+            sec2 = fminf(sec2, lbq); // dropped against the tighter bound: at least that far
+          else
+          {
+            pend_s[w][lane] = s;
+            pend_lb[w][lane] = h;
+            if (lbq < mlb)
+            {
+              mlb = lbq;
+              pick = w;
+            }
+            w++;
+          }
         }
+      }
+      npend = w;
+    };
+    // The picked triangle is screened (straight after purge(): it is still in the race), the
+    // last entry takes its slot.  Most promising first: the bound it leaves behind turns most
+    // of the others away unscreened.
+    auto screen_pick = [&]() {
+      const int32_t s = pend_s[pick][lane];
+      npend--;
+      if (pick != npend)
+      {
+        pend_s[pick][lane] = pend_s[npend][lane];
+        pend_lb[pick][lane] = pend_lb[npend][lane];
+      }
+      STAT(3, 1);
+      d3 P0, P1, P2;
+      load_tri(a.tverts, s, P0, P1, P2);
+      const double d2 = tri_d2_screen(x, P0, P1, P2);
+      sec2 = note_screened(sec2, d2, best, bound, tau, cnt);
+      if (d2 < best)
+        set_best(d2);
+      if (d2 <= bound)
+      {
+        if (cnt < RING3)
+          ring[cnt][lane] = s;
+        cnt++;
       }
     };
 
@@ -1221,12 +1275,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
             if (__ballot(want) == 0ull)
               continue;
             STAT(1, lane == 0 ? 1 : 0);
-            // room for this leaf in every lane's queue: screen until there is
-            while (__ballot(npend > PENDW - L) != 0ull)
+            // room for this leaf in every lane's queue: weed, and screen while that is not
+            // enough (every lane with something queued joins in: the instructions are spent
+            // anyway)
+            if (__ballot(npend > PENDW - L) != 0ull)
             {
-              STAT(4, lane == 0 ? 1 : 0);
-              if (npend > 0)
-                screen_one();
+              purge();
+              while (__ballot(npend > PENDW - L) != 0ull)
+              {
+                STAT(4, lane == 0 ? 1 : 0);
+                if (npend > 0)
+                  screen_pick();
+                purge();
+              }
             }
             const int64_t s0 = (int64_t)(cbase + c - (1u << d)) * L;
             if (s0 >= a.nt)
@@ -1237,40 +1298,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
 #pragma unroll
             for (int t = 0; t < 2 * L; t++)
               rec[t] = tpre4[2 * s0 + t];
+            // the centroids' distances are upper bounds of the triangles': the smallest met
+            // so far bounds the query's result before anything has been screened
+            float vx[L], vy[L], vz[L], q2[L];
+            float ubn = ubq;
+#pragma unroll
+            for (int t = 0; t < L; t++)
+            {
+              const vec4f rb = rec[2 * t + 1];
+              vx[t] = xf - rb.x;
+              vy[t] = yf - rb.y;
+              vz[t] = zf - rb.z;
+              q2[t] = __builtin_fmaf(vz[t], vz[t], __builtin_fmaf(vy[t], vy[t], vx[t] * vx[t]));
+              ubn = fminf(ubn, rec[2 * t].w < 0.f ? FLT_MAX : q2[t]);
+            }
+            if (__ballot(active && ubn < ubq) != 0ull)
+            {
+              if (active && ubn < ubq)
+              {
+                ubq = ubn;
+                const float vhi = __builtin_amdgcn_sqrtf(ubn) * 1.000001f + 2.f * eabs;
+                ubf = vhi * vhi * 1.000001f;
+                retighten();
+              }
+            }
+            // plane distance and in-plane distance to the circle about the centroid: the
+            // lower bound every triangle of an entered leaf is held against (a cheaper
+            // first test on the centroid alone let through three triangles of four: some
+            // lane of 64 is near enough to most triangles of a leaf its wavefront enters)
 #pragma unroll
             for (int t = 0; t < L; t++)
             {
               const vec4f ra = rec[2 * t], rb = rec[2 * t + 1];
               if (ra.w < 0.f)
                 continue;
-              // first the centroid alone: its distance is an upper bound of the triangle's,
-              // and less the radius a lower one, which for a query many triangle widths
-              // off the surface is nearly as sharp as the plane-and-circle bound
-              const float vx = xf - rb.x, vy = yf - rb.y, vz = zf - rb.z;
-              const float q2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
-              if (active && q2 < ubq)
+              STAT(6, lane == 0 ? 1 : 0);
+              const float lb = tri_lb_rec(ra.x, ra.y, ra.z, ra.w, rb.w, vx[t], vy[t], vz[t], q2[t], eabs);
+              if (want && lb > prunef)
+                sec2 = fminf(sec2, lb); // turned away: at least this far
+              if (want && lb <= prunef && (int32_t)(s0 + t) != hs_used)
               {
-                ubq = q2;
-                const float vhi = __builtin_amdgcn_sqrtf(q2) * 1.000001f + 2.f * eabs;
-                ubf = vhi * vhi * 1.000001f;
-                retighten();
-              }
-              const float reach = rpf + rb.w + 3.f * eabs;
-              const bool near = want && q2 * 0.999998f <= reach * reach * 1.000001f;
-              if (want && !near) // turned away by its centroid: at least this far
-                minlin = fminf(minlin, __builtin_amdgcn_sqrtf(q2) * 0.999999f - (rb.w + 3.f * eabs));
-              if (__ballot(near) == 0ull)
-                continue;
-              float lb, ub;
-              tri_bounds_rec<true>(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, xf, yf, zf, eabs,
-                lb, ub);
-              if (near && lb > prunef)
-                sec2 = fminf(sec2, lb); // turned away by the plane-and-circle bound
-              if (near && lb <= prunef && (int32_t)(s0 + t) != hs_used)
-              {
-                const int slot = (phead + npend) & (PENDW - 1);
-                pend_s[slot][lane] = (int32_t)(s0 + t);
-                pend_lb[slot][lane] = (uint16_t)(__float_as_uint(lb) >> 16);
+                pend_s[npend][lane] = (int32_t)(s0 + t);
+                pend_lb[npend][lane] = (uint16_t)(__float_as_uint(lb) >> 16);
                 npend++;
               }
             }
@@ -1307,11 +1376,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
       }
     }
     // what is still queued, against the bounds as they stand at the end of the walk
+    purge();
     while (__ballot(npend > 0) != 0ull)
     {
       STAT(5, lane == 0 ? 1 : 0);
       if (npend > 0)
-        screen_one();
+        screen_pick();
+      purge();
     }
 
     // settle: a single contender wins outright; 2..RING3 go to the tie list; more overflow
@@ -1320,7 +1391,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     if (active && !tie && !ovf)
       a.hint[q] = (cnt == 1) ? ring[0][lane] : -1;
     if (active && cert)
-      cert[q] = make_certificate(cnt, best, sec2, minraw, minlin, tau, eabs, a.cap2);
+      cert[q] = make_certificate(cnt, best, sec2, minraw, INFINITY, tau, eabs, a.cap2);
     const unsigned long long mt = __ballot(tie);
     if (mt)
     {
@@ -1359,6 +1430,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
   atomicAdd(&g_stats[3], st_3);
   atomicAdd(&g_stats[4], st_4);
   atomicAdd(&g_stats[5], st_5);
+  atomicAdd(&g_stats[6], st_6);
+  atomicAdd(&g_stats[7], st_7);
 #endif
 }
 

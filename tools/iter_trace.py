@@ -10,6 +10,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from iterativeclosestpoint_amd import icpx, synth  # noqa: E402
 
 
+def stats_read(ctx):
+    """Traversal counters of a development build (make -C .../csrc stats; ICPX_LIB=...)."""
+    import ctypes
+    lib = icpx.load()
+    if not hasattr(lib, "icpx_stats_read"):
+        return None
+    out = (ctypes.c_ulonglong * 8)()
+    lib.icpx_stats_read(ctypes.c_void_p(ctx._h.value if hasattr(ctx._h, "value") else ctx._h), out)
+    return list(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c3")
@@ -51,6 +62,15 @@ def main():
                 print("it %2d  wall %.3f  search %.3f  finalize %.3f  n %d  mean %.3e  %s" %
                       (it, wall, s_ms - ps, f_ms - pf, n, md, ctx.debug_counters()), flush=True)
             ps, pf = s_ms, f_ms
+            st = stats_read(ctx)
+            if st is not None and rep == 1:
+                nw = len(c["source_xyz"]) / 64.0
+                print("       per wavefront of a whole k_search3w pass: node steps %.1f (nobody "
+                      "interested %.1f)  leaves %.1f  screen rounds %.1f + %.1f;  screens per query %.2f"
+                      % (st[0] / nw, st[2] / nw, st[1] / nw, st[4] / nw, st[5] / nw,
+                         st[3] / len(c["source_xyz"])), flush=True)
+                print("       triangles met %.1f, of which some lane took the plane-and-circle bound "
+                      "%.1f" % (st[6] / nw, st[7] / nw), flush=True)
         ctx.set_timing(False)
 
 
