@@ -75,7 +75,8 @@ extern "C"
    * 1e9, list entries, passes whose certificates were checked by the light kernel, passes
    * that enqueued both tree kernels over the leftovers, and of a run's such passes how many
    * the wavefront walk served and how many the pooled lanes, cells the last
-   * icpx_point_normals reversed for consistent winding} (10 x int64); 5: the shortcut's
+   * icpx_point_normals reversed for consistent winding, passes that sent the light
+   * kernel's list straight to the tree kernels} (11 x int64); 5: the shortcut's
    * certificates (float per query of
    * this shard: how far the query may still move before its winner is looked at again,
    * 0 = none, negative = how far before something may come within the distance threshold;

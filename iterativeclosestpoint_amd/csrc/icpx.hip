@@ -122,7 +122,7 @@ __global__ void k_solve(RunState* s, const double* __restrict__ sums, int metric
     return;
   const double origin[3] = { ox, oy, oz };
   solve_and_publish(s, sums, metric, origin, check_mean, max_mean, true, counters ? counters[7] : 0u,
-    rec, seq);
+    counters ? counters[8] : 0u, rec, seq);
 }
 
 // The reduction and the solve in one launch, for a loop with nothing between them (one
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
   *ticket = 0u;
   const double origin[3] = { ox, oy, oz };
   solve_and_publish(s, tot, metric, origin, check_mean, max_mean, ran, counters ? counters[7] : 0u,
-    rec, seq);
+    counters ? counters[8] : 0u, rec, seq);
 }
 
 // ---- icpx_accumulate_static: scratch that lives in the code object, not on the heap ----
@@ -262,6 +262,9 @@ struct icpx_ctx
   double last_mean = 0.0;
   int local_holdoff = 0; // passes to go without the shortcut (it served too few queries)
   int bad_streak = 0;    // consecutive passes it served too few queries while the residual was large
+  int hopeless_streak = 0; // consecutive listed passes in which it settled less than half of its list
+  bool direct = false;     // k_certify's list goes straight to the tree kernels (see note_pass)
+  int direct_passes = 0;
   int use_cert = 1;      // the shortcut keeps certificates (icpx_set_local(2) turns them off)
   int holdoff_len = 8;   // length of the next suspension: doubles each time one is called for
   bool after_cold = false; // the last pass was a cold one
@@ -276,6 +279,9 @@ struct icpx_ctx
   bool last_local = false;   // the pass enqueued last tried the shortcut
   bool stat_local = false;   // ... and so did the pass whose figures are pending in h_stat
   bool pass_local[4] = { false, false, false, false }; // ... and the run's passes, by record slot
+  bool last_listed = false;  // the pass just enqueued ran the shortcut over k_certify's list
+  bool stat_listed = false;
+  bool pass_listed[4] = { false, false, false, false };
   // device-resident loop
   RunState* d_state = nullptr;
   RunRecord* h_rec = nullptr; // pinned ring of the last four iterations' records
@@ -816,10 +822,10 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
   }
   else if (what == 4)
   {
-    int64_t v[10] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
+    int64_t v[11] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
       c->nbr_total, c->certify_passes, c->split_passes, c->split_wave, c->split_pool,
-      c->last_flips };
-    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 10));
+      c->last_flips, c->direct_passes };
+    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 11));
     return ICPX_OK;
   }
   else if (what == 3 && c->d_ovf_best)
@@ -880,6 +886,8 @@ extern "C" int icpx_set_local(icpx_ctx* c, int enable)
   c->certify_min = enable == 3 ? 0 : CERTIFY_MIN; // 3: certificates checked by their own kernel at any size
   c->local_holdoff = 0; // (and the policy starts afresh)
   c->bad_streak = 0;
+  c->hopeless_streak = 0;
+  c->direct = false;
   c->holdoff_len = 8;
   c->probation = false;
   return ICPX_OK;
@@ -923,6 +931,8 @@ extern "C" int icpx_reset_hints(icpx_ctx* c)
   c->stat_pending = false;
   c->local_holdoff = 0;
   c->bad_streak = 0;
+  c->hopeless_streak = 0;
+  c->direct = false;
   c->holdoff_len = 8;
   c->probation = false;
   return ICPX_OK;
@@ -1619,10 +1629,21 @@ static int ensure_lists(icpx_ctx* c)
 }
 
 // A finished pass's figures, for the shortcut's policy (see prepare_local).
-static void note_pass(icpx_ctx* c, double n, double mean, double fallback, bool was_local)
+static void note_pass(icpx_ctx* c, double n, double mean, double fallback, double listed,
+  bool was_local, bool was_listed)
 {
   if (!was_local)
     return; // a pass without the shortcut says nothing about it
+  // The shortcut run over k_certify's list: when it settles less than half of a list of
+  // some length twice in a row (a noisy cloud: its points are farther from the surface than
+  // the neighbour lists reach, whatever the pose), the list goes straight to the tree
+  // kernels from then on, until the next cold start.
+  if (was_listed && listed >= 1024.0)
+  {
+    c->hopeless_streak = fallback >= 0.5 * listed ? c->hopeless_streak + 1 : 0;
+    if (c->hopeless_streak >= 2)
+      c->direct = true;
+  }
   const bool bad = n > 0.0 && fallback > 0.5 * (double)c->nq && 3.0 * mean > (double)c->nbr_eps;
   c->bad_streak = bad ? c->bad_streak + 1 : 0;
   if (!bad && c->local_holdoff == 0)
@@ -1666,7 +1687,7 @@ static int prepare_local(icpx_ctx* c, bool* use)
   {
     c->stat_pending = false;
     note_pass(c, c->h_stat[0], c->h_stat[0] > 0.0 ? c->h_stat[1] / c->h_stat[0] : 0.0,
-      c->h_stat[2], c->stat_local);
+      c->h_stat[2], c->h_stat[3], c->stat_local, c->stat_listed);
   }
   if (c->local_holdoff > 0)
   {
@@ -1741,6 +1762,7 @@ static int run_search3(icpx_ctx* c)
   if (rc)
     return rc;
   c->last_local = use_local;
+  c->last_listed = false;
   // by regime: a whole pass over a cloud about as dense as the mesh goes one walk per
   // wavefront (neighbouring queries share their walk); what the shortcut left over, or a
   // sparse cloud, is scattered and goes one pooled lane per query
@@ -1784,6 +1806,7 @@ static int run_search3(icpx_ctx* c)
     la.work_count = nullptr;
     la.segcap = 0;
     unsigned lgrid = grid;
+    bool listed = false;
     // a large cloud with certificates from the last pass: those are checked by a light
     // kernel of their own, and the shortcut serves the ones that failed
     if (a.cert && c->certs_live && a.use_hint && c->certify_min >= 0 && c->nq >= c->certify_min)
@@ -1805,6 +1828,9 @@ static int run_search3(icpx_ctx* c)
       const unsigned cgrid = nblk(c->nq, 256 * ca.rounds);
       ca.segcap = (int64_t)((cgrid + CERTIFY_SEGS - 1) / CERTIFY_SEGS) * 256 * ca.rounds;
       ca.setmask = c->d_setmask;
+      listed = !c->direct;
+      ca.direct = listed ? nullptr : c->d_fallback;
+      ca.direct_count = c->d_counters + 3;
       launch_ev(c, false, k_certify, cgrid, 256, st, ca);
       c->certify_passes++;
       la.work = c->d_work;
@@ -1816,12 +1842,15 @@ static int run_search3(icpx_ctx* c)
       if (lgrid > cap)
         lgrid = cap;
     }
-    if (la.work)
+    if (la.work && !listed)
+      c->direct_passes++; // (the list is the tree kernels' as it is, winners of the last pass as hints)
+    else if (la.work)
       launch_ev(c, false, k_search_local<true>, lgrid, 256, st, la);
     else
       launch_ev(c, false, k_search_local<false>, lgrid, 256, st, la);
     a.qlist = c->d_fallback; // the tree kernel serves what is left,
     a.use_hint = 1;          // starting from the triangles the shortcut reached
+    c->last_listed = listed;
     c->local_passes++;
   }
   else
@@ -1886,6 +1915,7 @@ static void set_cap(icpx_ctx* c, double max_dist)
 static int run_search(icpx_ctx* c)
 {
   c->last_local = false;
+  c->last_listed = false;
   c->last_split = false;
   c->certs_live = c->pass_certs && c->hint_valid; // (what the last pass left)
   c->pass_certs = false;
@@ -2072,6 +2102,7 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
       p.max_mean_distance, c->d_rec + slot, ++c->rec_seq, c->d_ticket, c->cap2);
     c->slot_seq[slot] = c->rec_seq;
     c->pass_local[slot] = c->last_local;
+    c->pass_listed[slot] = c->last_listed;
     c->pass_split[slot] = c->last_split;
     c->run_it++;
   }
@@ -2087,6 +2118,7 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     HIPCHK(hipEventRecord(c->ev_stat, st));
     c->stat_pending = true;
     c->stat_local = c->last_local;
+    c->stat_listed = c->last_listed;
   }
   return ICPX_OK;
 }
@@ -2601,6 +2633,8 @@ extern "C" int icpx_run_begin(icpx_ctx* c, const icpx_params* p)
   c->stat_pending = false;
   c->local_holdoff = 0;
   c->bad_streak = 0;
+  c->hopeless_streak = 0;
+  c->direct = false;
   c->holdoff_len = 8;
   c->probation = false;
   double I[16];
@@ -2664,7 +2698,8 @@ static int run_catch_up(icpx_ctx* c)
   const RunRecord& r = c->h_rec[slot];
   if (r.done)
     c->run_done_known = true;
-  note_pass(c, r.n, r.mean, (double)r.fallback, c->pass_local[slot]);
+  note_pass(c, r.n, r.mean, (double)r.fallback, (double)r.listed, c->pass_local[slot],
+    c->pass_listed[slot]);
   tally_split(c, slot);
   return ICPX_OK;
 }
@@ -2708,7 +2743,8 @@ extern "C" int icpx_run_update(icpx_ctx* c, const double* sums_device)
   LAUNCHCHK();
   c->slot_seq[slot] = c->rec_seq;
   c->pass_local[slot] = c->last_local;
-    c->pass_split[slot] = c->last_split;
+  c->pass_listed[slot] = c->last_listed;
+  c->pass_split[slot] = c->last_split;
   c->run_it++;
   return ICPX_OK;
 }

@@ -666,6 +666,10 @@ struct CertifyArgs
   int64_t segcap;
   int rounds; // queries per block / 256 (1 .. CERTIFY_ROUNDS)
   unsigned long long* setmask; // one bit per query: passed, and stands on a set certificate
+  // not null: the failed queries go on this one dense list (length *direct_count), straight
+  // for the tree kernels, instead of the segmented one for the shortcut
+  uint32_t* direct;
+  uint32_t* direct_count;
 };
 
 constexpr int CERTIFY_ROUNDS = 16;
@@ -751,10 +755,12 @@ __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
       wcount[i] = run;
       run += v;
     }
-    bbase = run ? atomicAdd(&c.work_count[seg * CERTIFY_SEG_STRIDE], run) : 0u;
+    bbase = !run ? 0u
+      : c.direct ? atomicAdd(c.direct_count, run)
+                 : atomicAdd(&c.work_count[seg * CERTIFY_SEG_STRIDE], run);
   }
   __syncthreads();
-  uint32_t* const work = c.work + seg * c.segcap;
+  uint32_t* const work = c.direct ? c.direct : c.work + seg * c.segcap;
   for (int k = 0; k < rounds; k++)
   {
     const int64_t q = first + (int64_t)k * 256;

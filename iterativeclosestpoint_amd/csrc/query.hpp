@@ -529,10 +529,28 @@ __device__ __forceinline__ bool reduce_partials_body(
     if (stat && l == 3)
       stat[2] = (double)old; // shortcut fallbacks of this pass
   }
-  if (counters && i == 0 && l < 32)
-    counters[16 + l * 64] = 0u; // the lengths of the segments of k_certify's list
+  if (counters && i == 0)
+  {
+    // the lengths of the segments of k_certify's list: their sum moves up beside the other
+    // counts, and they are left at zero
+    uint32_t len = l < 32 ? counters[16 + l * 64] : 0u;
+    if (l < 32)
+      counters[16 + l * 64] = 0u;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1)
+      len += __shfl_xor(len, m, 64);
+    if (l == 0)
+    {
+      counters[8] = len;
+      if (stat)
+        stat[3] = (double)len;
+    }
+  }
   if (stat && !counters && i == 0 && l == 0)
+  {
     stat[2] = 0.0;
+    stat[3] = 0.0;
+  }
   double v = 0.0;
   for (int b = l; b < nblocks; b += 64)
     v += partials[(int64_t)b * ICPX_NSUMS + i];

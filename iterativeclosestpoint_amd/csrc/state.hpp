@@ -30,19 +30,20 @@ struct RunRecord
   int32_t iters, status, done;
   uint32_t fallback;
   uint32_t seq; // the solve's serial number, stored after the rest: the host waits for it
-  uint32_t pad_;
+  uint32_t listed; // queries on k_certify's list of failed certificates in that pass (0: no such list)
 };
 // One iteration's solve and transform update in a single GPU thread: the body of the
 // loop in vtkICP::InternalUpdate after the correspondence filter (ICP/vtkICP.cxx:218-245),
 // and the iteration's record for the host, written straight to pinned host memory, where
 // the host finds it two iterations later by its serial number (no event, hence no marker
 // in the queue between iterations).  run: this pass ran and the registration is not over;
-// fallback_now: the pass's count of queries the shortcut left to the tree walk.
+// fallback_now: the pass's count of queries the shortcut left to the tree walk; listed_now:
+// the length of k_certify's list in that pass.
 // (Everything the step reads is requested at once and the record is written from
 // registers: one lane's chain of dependent reads is what this costs.)
 __device__ inline void solve_and_publish(RunState* s, const double* __restrict__ sums, int metric,
   const double* origin, int check_mean, double max_mean, bool ran, uint32_t fallback_now,
-  RunRecord* rec, uint32_t seq)
+  uint32_t listed_now, RunRecord* rec, uint32_t seq)
 {
   double Tm[16];
 #pragma unroll
@@ -94,6 +95,7 @@ __device__ inline void solve_and_publish(RunState* s, const double* __restrict__
   rec->status = status;
   rec->done = done;
   rec->fallback = fallback;
+  rec->listed = ran ? listed_now : 0u;
   __threadfence_system();
   *reinterpret_cast<volatile uint32_t*>(&rec->seq) = seq;
 }
