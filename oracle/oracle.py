@@ -106,7 +106,8 @@ class Mesh:
                                        len(self.tri), _ptr(self.cn))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        # (at interpreter shutdown the module's globals may be gone before the object)
+        if getattr(self, "h", None) and callable(lib):
             lib().orc_mesh_destroy(self.h)
             self.h = None
 

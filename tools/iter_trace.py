@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--refill", type=int, default=0)
     ap.add_argument("--local", type=int, default=1)
     ap.add_argument("--persistent", type=int, default=-1)
+    ap.add_argument("--certs", action="store_true", help="summarise the certificates after every pass")
     a = ap.parse_args()
     c = {"c3": synth.config_c3, "c4": synth.config_c4,
          "c5big": lambda: synth.config_c5(nu=1000, nv=500, npts=1_200_000)}[a.workload]()
@@ -46,6 +47,9 @@ def main():
     ctx.set_local(a.local)
     ctx.set_target(c["target_xyz"], c["target_tri"])
     ctx.set_source(c["source_xyz"], c["source_normals"])
+    lo, hi = c["source_xyz"].min(0), c["source_xyz"].max(0)
+    corners = np.array([[x, y, z, 1.0] for x in (lo[0], hi[0]) for y in (lo[1], hi[1])
+                        for z in (lo[2], hi[2])])
     for rep in range(2):
         ctx.reset_hints()
         T = np.eye(4)
@@ -55,13 +59,25 @@ def main():
             t0 = time.perf_counter()
             sums = ctx.accumulate(metric, T, 1, c["max_dist"])
             M, n, md, rc = icpx.solve(metric, sums, ctx.origin)
-            T = M @ T
+            Tn = M @ T
+            # how far this step moves the cloud (largest displacement of a corner of its box)
+            step_move = np.linalg.norm((corners @ (Tn - T).T)[:, :3], axis=1).max()
+            T = Tn
             wall = 1e3 * (time.perf_counter() - t0)
             s_ms, s_n, f_ms, f_n = ctx.get_timing()
             if rep == 1:
-                print("it %2d  wall %.3f  search %.3f  finalize %.3f  n %d  mean %.3e  %s" %
-                      (it, wall, s_ms - ps, f_ms - pf, n, md, ctx.debug_counters()), flush=True)
+                print("it %2d  wall %.3f  search %.3f  finalize %.3f  n %d  mean %.3e  step moves the "
+                      "cloud by %.2e  %s" %
+                      (it, wall, s_ms - ps, f_ms - pf, n, md, step_move, ctx.debug_counters()), flush=True)
             ps, pf = s_ms, f_ms
+            if a.certs and rep == 1:
+                cert = ctx.debug_certificates(len(c["source_xyz"]))
+                isset = (cert > 0) & ((cert.view(np.uint32) & 1) == 1)
+                print("       certificates after the pass: single %.4f  set %.4f  far %.4f  none %.4f;"
+                      "  median single %.2e  median set %.2e" %
+                      (((cert > 0) & ~isset).mean(), isset.mean(), (cert < 0).mean(), (cert == 0).mean(),
+                       np.median(cert[(cert > 0) & ~isset]) if ((cert > 0) & ~isset).any() else 0.0,
+                       np.median(cert[isset]) if isset.any() else 0.0), flush=True)
             st = stats_read(ctx)
             if st is not None and rep == 1:
                 nw = len(c["source_xyz"]) / 64.0
