@@ -71,6 +71,7 @@ struct Bin
 {
   BinTree t;
   float* nodes = nullptr;
+  float4* lpre = nullptr; // per-leaf bounds records (k_leaf_bounds)
   bool built = false;
 };
 
@@ -540,6 +541,7 @@ static void free_target(icpx_ctx* c)
   for (auto& t : c->bins)
   {
     dev_free(&t.nodes);
+    dev_free(&t.lpre);
     t.built = false;
   }
   dev_free(&c->d_noff);
@@ -1509,6 +1511,8 @@ static int ensure_bin(icpx_ctx* c, int L)
     c->d_tverts, c->d_tid, c->nt, b.t, b.nodes);
   for (int k = b.t.depth - 2; k >= 0; k--)
     k_bin_level<<<nblk(2ll << k, 256), 256, 0, st>>>(k, b.nodes);
+  ALLOC(b.lpre, 2 * b.t.nleaf);
+  k_leaf_bounds<<<nblk(b.t.nleaf, 256), 256, 0, st>>>(c->d_tverts, c->d_tid, c->nt, b.t, b.lpre);
   LAUNCHCHK();
   b.built = true;
   return ICPX_OK;
@@ -1732,6 +1736,7 @@ static int run_search3(icpx_ctx* c)
   a.tverts = c->d_tverts;
   a.tid = c->d_tid;
   a.tpre = c->d_tpre;
+  a.lpre = b.lpre;
   a.nt = c->nt;
   a.hint = c->d_hint;
   a.use_hint = c->hint_valid ? 1 : 0;

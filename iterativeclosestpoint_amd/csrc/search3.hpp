@@ -157,6 +157,78 @@ __global__ void k_tri_bounds(const float* __restrict__ tverts, const int32_t* __
   pre[2 * s + 1] = make_float4(cx, cy, cz, R);
 }
 
+// Per leaf of a tree with L triangles per leaf, the same kind of record for the leaf's whole
+// patch of surface: the unit normal of the patch (normalised sum of its triangles' area
+// vectors; zero when that cannot be trusted), the half thickness of the slab about the
+// stored centre, across that normal, that holds every point of its triangles, then the
+// centre and the radius of the sphere about it that holds them.  An axis-aligned box
+// around a slanted patch is thick, and a query many triangle widths off the surface then
+// has dozens of leaf boxes within its bound; the slab of a smooth patch is a few percent of
+// its width thick whatever its slant.  A leaf without a usable triangle carries -1 as its
+// half thickness.
+__global__ void k_leaf_bounds(const float* __restrict__ tverts, const int32_t* __restrict__ tid,
+  int64_t nt, BinTree t, float4* __restrict__ lpre)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t.nleaf)
+    return;
+  const int64_t s0 = i * t.L, s1 = min(nt, s0 + t.L);
+  d3 c = mk(0.0, 0.0, 0.0), n = mk(0.0, 0.0, 0.0);
+  int cnt = 0;
+  double emax2 = 0.0;
+  for (int64_t s = s0; s < s1; s++)
+  {
+    if (tid[s] < 0)
+      continue;
+    d3 P0, P1, P2;
+    load_tri(tverts, s, P0, P1, P2);
+    c = mk(c.x + P0.x + P1.x + P2.x, c.y + P0.y + P1.y + P2.y, c.z + P0.z + P1.z + P2.z);
+    const d3 e1 = mk(P1.x - P0.x, P1.y - P0.y, P1.z - P0.z);
+    const d3 e2 = mk(P2.x - P0.x, P2.y - P0.y, P2.z - P0.z);
+    n = mk(n.x + (e1.y * e2.z - e1.z * e2.y), n.y + (e1.z * e2.x - e1.x * e2.z),
+      n.z + (e1.x * e2.y - e1.y * e2.x));
+    emax2 = fmax(emax2, fmax(dot3(e1, e1), dot3(e2, e2)));
+    cnt++;
+  }
+  if (cnt == 0)
+  {
+    lpre[2 * i] = make_float4(0.f, 0.f, 0.f, -1.f);
+    lpre[2 * i + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const float cx = (float)(c.x / (3.0 * cnt)), cy = (float)(c.y / (3.0 * cnt)),
+              cz = (float)(c.z / (3.0 * cnt));
+  const d3 cf = mk((double)cx, (double)cy, (double)cz); // the centre as stored
+  const double len = sqrt(dot3(n, n));
+  // (area vectors that cancel, or a patch of slivers: no direction to speak of)
+  const bool ok = len > 1e-6 * emax2;
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  if (ok)
+  {
+    nx = (float)(n.x / len);
+    ny = (float)(n.y / len);
+    nz = (float)(n.z / len);
+  }
+  double r2 = 0.0, half = 0.0;
+  for (int64_t s = s0; s < s1; s++)
+  {
+    if (tid[s] < 0)
+      continue;
+    d3 P[3];
+    load_tri(tverts, s, P[0], P[1], P[2]);
+    for (int k = 0; k < 3; k++)
+    {
+      r2 = fmax(r2, dist2(P[k], cf));
+      // every point of the patch is a convex combination of these: its offset along the
+      // stored normal lies between the smallest and the largest of theirs
+      half = fmax(half, fabs((double)nx * (P[k].x - cf.x) + (double)ny * (P[k].y - cf.y) +
+                               (double)nz * (P[k].z - cf.z)));
+    }
+  }
+  lpre[2 * i] = make_float4(nx, ny, nz, __double2float_ru(half * (1.0 + 1e-6) + 1e-300));
+  lpre[2 * i + 1] = make_float4(cx, cy, cz, __double2float_ru(sqrt(r2) * (1.0 + 1e-12)));
+}
+
 struct Search3Args
 {
   const float* qpos;
@@ -170,6 +242,7 @@ struct Search3Args
   const float* tverts;
   const int32_t* tid;
   const float4* tpre; // per-triangle bounds records (k_tri_bounds), used by k_search3w
+  const float4* lpre; // per-leaf bounds records of this tree (k_leaf_bounds), used by k_search3w
   int64_t nt;
   int32_t* hint;
   int use_hint;
@@ -966,6 +1039,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
   }
   cfloat4* nodes4 = (cfloat4*)(uintptr_t)a.nodes;
   cfloat4* tpre4 = (cfloat4*)(uintptr_t)a.tpre;
+  cfloat4* lpre4 = (cfloat4*)(uintptr_t)a.lpre;
 #ifdef ICPX_STATS
   unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0, st_6 = 0, st_7 = 0;
 #endif
@@ -1269,7 +1343,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
             k2 = k3;
             k3 = 0xffffffffu;
             const float lbc = c == 0u ? lb0 : c == 1u ? lb1 : c == 2u ? lb2 : lb3;
-            const bool want = lbc <= bboxf;
+            bool want = lbc <= bboxf;
             if (!want)
               minraw = fminf(minraw, lbc); // (the bound may have shrunk since the node's visit)
             if (__ballot(want) == 0ull)
@@ -1289,15 +1363,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
                 purge();
               }
             }
-            const int64_t s0 = (int64_t)(cbase + c - (1u << d)) * L;
+            const int64_t leaf = (int64_t)(cbase + c - (1u << d));
+            const int64_t s0 = leaf * L;
             if (s0 >= a.nt)
               continue; // a leaf past the last triangle
             // (the leaf's records are contiguous, padded past the end, and say themselves
-            // whether the triangle counts; all are requested at once)
+            // whether the triangle counts; all are requested at once, the leaf's own with them)
+            const vec4f la_ = lpre4[2 * leaf], lb_ = lpre4[2 * leaf + 1];
             vec4f rec[2 * L];
 #pragma unroll
             for (int t = 0; t < 2 * L; t++)
               rec[t] = tpre4[2 * s0 + t];
+            // The leaf's patch of surface between two planes and inside a sphere: a box
+            // around a slanted patch is thick, and a query many triangle widths off the
+            // surface has dozens of leaf boxes within its bound, but few slabs.
+            if (la_.w >= 0.f)
+            {
+              const float ux = xf - lb_.x, uy = yf - lb_.y, uz = zf - lb_.z;
+              const float u2 = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+              const float lbl = tri_lb_rec(la_.x, la_.y, la_.z, la_.w, lb_.w, ux, uy, uz, u2, eabs);
+              if (want && lbl > prunef)
+              {
+                want = false;
+                sec2 = fminf(sec2, lbl); // every triangle of the leaf is at least this far
+              }
+              if (__ballot(want) == 0ull)
+                continue;
+              STAT(7, lane == 0 ? 1 : 0);
+            }
             // the centroids' distances are upper bounds of the triangles': the smallest met
             // so far bounds the query's result before anything has been screened
             float vx[L], vy[L], vz[L], q2[L];
