@@ -9,6 +9,8 @@ when more than one rank), solve and transform update on the device.  --steps K t
 K such registrations after --warmup W untimed ones; because a step always contains the same
 work (one cold pass, a few displaced passes, the converged rest), `value` does not depend on
 K.  The K registrations are also timed one by one: median and spread are in `config`.
+The search kernels of every fourth of them (--timing-every) carry HIP events, for the
+`roofline` object's per-phase kernel times.
 
 Workloads.  c3 (default, the configuration the headline metric names): the synthetic
 1,000,000-triangle bumpy torus against 1,000,000 area-uniform surface samples moved by
@@ -88,6 +90,8 @@ def main():
                     help="development: one rank, but through the multi-rank loop with its all-reduce")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="development: leave out the HIP events around the search kernels")
+    ap.add_argument("--timing-every", type=int, default=4,
+                    help="the search kernels of every N-th timed registration carry HIP events")
     args = ap.parse_args()
 
     # Only the result line may reach stdout: libraries underneath (RCCL's version banner,
@@ -162,18 +166,30 @@ def main():
 
     for _ in range(args.warmup):
         registration()
-    sh.ctx.set_timing(0 if args.no_kernel_timing else 2)  # the search kernels only
+    # The search kernels of every `timing_every`-th timed registration carry HIP events (the
+    # first and the last search kernel of each pass, on the library's stream).  Not of every
+    # one: a kernel with a completion event holds the next kernel back by ~5 us, three times
+    # per pass, 6 % of a registration of the default workload.
+    every = 0 if args.no_kernel_timing else max(1, args.timing_every)
+    sh.ctx.set_timing(0)
     fence()
-    each = []
+    each, timed, pass_rows = [], [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        with_events = every > 0 and i % every == 0
+        if with_events:
+            sh.ctx.set_timing(2)       # the search kernels only
         t1 = time.perf_counter()
         T, mean_d = registration()     # (returns when the last iteration's transform is back)
         each.append(time.perf_counter() - t1)
+        timed.append(with_events)
+        if with_events:
+            pm_, _, _ = sh.ctx.get_pass_timings()
+            if len(pm_) == ITERATIONS:
+                pass_rows.append(pm_)
+            sh.ctx.set_timing(0)
     fence()
     elapsed = time.perf_counter() - t0
-    pass_ms, pass_kind, pass_hinted = sh.ctx.get_pass_timings()
-    sh.ctx.set_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device="cuda" if args.backend == "nccl" else "cpu")
@@ -223,6 +239,9 @@ def main():
                 "registration_ms_median": float(1e3 * np.median(each)),
                 "registration_ms_min": float(1e3 * each.min()),
                 "registration_ms_max": float(1e3 * each.max()),
+                "registration_ms_median_with_kernel_events":
+                    float(1e3 * np.median(each[np.array(timed)])) if any(timed) else None,
+                "registrations_with_kernel_events": int(sum(timed)),
                 "mean_distance_last_iteration": float(mean_d),
                 "residual_vs_truth": float(np.abs(T @ c["truth"] - np.eye(4)).max())
                 if "truth" in c else None,
@@ -232,10 +251,9 @@ def main():
                 "one_rank_check_rel": one_rank_check,
             },
         }
-        if len(pass_ms) == ITERATIONS * args.steps:
-            # rank 0's search kernels, pass by pass (HIP events riding on the first and the
-            # last search kernel of every pass, on the library's stream)
-            pm = pass_ms.reshape(args.steps, ITERATIONS)
+        if pass_rows:
+            # rank 0's search kernels, pass by pass, of the registrations that carried events
+            pm = np.array(pass_rows)
             cold = float(np.median(pm[:, 0]))                       # k_search3w, cold start
             steady = float(np.median(pm[:, ITERATIONS // 2:]))      # converged passes
             b_struct = structure_bytes(nv, nt)
@@ -258,7 +276,7 @@ def main():
                 "traffic": None,
                 "algorithmic_bytes_per_launch": b_cold,
                 "kernel_ms": cold,
-                "launches": int(args.steps),
+                "launches": int(len(pass_rows)),
                 "phases": {
                     "cold_pass": {"kernels": "k_search3w + k_contested", "ms": cold,
                                   "algorithmic_bytes": b_cold, "achieved_GBs": ach_cold,

@@ -389,7 +389,9 @@ static hipEvent_t take_event(icpx_ctx* c)
     e = c->free_events.back();
     c->free_events.pop_back();
   }
-  else if (hipEventCreate(&e) != hipSuccess)
+  // (a device-scope release: these events only time kernels, nobody on the host waits for
+  // memory behind them, and the default system-scope release holds the next kernel back)
+  else if (hipEventCreateWithFlags(&e, hipEventReleaseToDevice) != hipSuccess)
     e = nullptr;
   return e;
 }

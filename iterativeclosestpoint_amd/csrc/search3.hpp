@@ -911,8 +911,10 @@ __global__ __launch_bounds__(256) void k_search3p(Search3Args a)
 // pooled lanes.  Same results either way.
 constexpr uint32_t FALLBACK_SMALL = 98304;
 
+// (128 registers: four wavefronts per SIMD; the walks are latency-bound, and the one more
+// register set the compiler would like to have costs a quarter of the walks in flight)
 template <int L>
-__global__ __launch_bounds__(256) void k_fallback(Search3Args a, Search2Args w)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_fallback(Search3Args a, Search2Args w)
 {
   const uint32_t total = a.counters[3];
   if (total == 0u || (int64_t)total < a.list_lo || (int64_t)total >= a.list_hi)
