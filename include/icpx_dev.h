@@ -58,6 +58,12 @@ extern "C"
    * Same results. */
   int icpx_set_refill(icpx_ctx* ctx, int lanes);
 
+  /* The fused finalize: 0 (default) = by the size of the cloud; 1 = the build that keeps the
+   * metric's sums in registers; 2 = the build that accumulates them on the matrix core
+   * (v_mfma_f64_16x16x4_f64 over a 16-vector per row).  The two add the rows up in different
+   * orders: the sums agree to rounding (1e-13 relative), not to the last bit. */
+  int icpx_set_finalize(icpx_ctx* ctx, int build);
+
   /* Search kernel selection.  0 (default): the production kernel, which screens
    * triangles with a short fp64 routine and evaluates only near-ties (within
    * 1e-9 x the largest coordinate of the minimum) with the reference's exact

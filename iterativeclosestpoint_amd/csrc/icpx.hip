@@ -248,6 +248,7 @@ struct icpx_ctx
   // of the previous pass that choose the radius
   int use_local = 1;
   int refill_override = 0; // pooled kernels' refill threshold (0 = by regime)
+  int finalize_build = 0;  // fused finalize: 0 by size, 1 register sums, 2 matrix core
   int nbr_state = 0;    // 0 not tried, 1 built, -1 not worth it for this mesh
   float nbr_eps = 0.f;  // radius the lists cover
   float mesh_edge = 0.f; // typical edge length of the target (sampled)
@@ -904,6 +905,16 @@ extern "C" int icpx_set_refill(icpx_ctx* c, int lanes)
   if (lanes < 0 || lanes > 64)
     return fail(ICPX_E_INVALID, "refill threshold must be 0 (by regime) or 1..64 lanes (got %d)", lanes);
   c->refill_override = lanes;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_finalize(icpx_ctx* c, int build)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  if (build < 0 || build > 2)
+    return fail(ICPX_E_INVALID, "finalize build must be 0 (by size), 1 (registers) or 2 (matrix core), got %d", build);
+  c->finalize_build = build;
   return ICPX_OK;
 }
 
@@ -1919,6 +1930,44 @@ static void set_cap(icpx_ctx* c, double max_dist)
   c->cap2 = (max_dist > 0.0 && max_dist < 1e100) ? max_dist * max_dist * (1.0 + 1e-12) : DBL_MAX;
 }
 
+// The fused finalize: which build (see query.hpp) and how many blocks.  Up to four million
+// rows every lane of a resident grid has at most a few to do and the matrix-core build is the
+// faster one; beyond, the register build.
+constexpr int64_t FINALIZE_MX_MAX = 4000000;
+static bool finalize_on_matrix_core(const icpx_ctx* c, int64_t nq)
+{
+  return c->finalize_build == 0 ? nq <= FINALIZE_MX_MAX : c->finalize_build == 2;
+}
+static int finalize_grid(const icpx_ctx* c, int64_t nq)
+{
+  const int per_cu = finalize_on_matrix_core(c, nq) ? 4 : 3; // wavefronts per SIMD = resident blocks per CU
+  int grid = (int)nblk(nq, FIN_THREADS);
+  if (grid > c->num_cus * per_cu)
+    grid = c->num_cus * per_cu;
+  if (grid > c->max_blocks)
+    grid = c->max_blocks;
+  return grid;
+}
+static void launch_finalize_sums(const icpx_ctx* c, int metric, const FinalArgs& f, int64_t nq,
+  int grid, hipStream_t st)
+{
+  if (finalize_on_matrix_core(c, nq))
+  {
+    if (metric == 0)
+      k_finalize_mx<0, false><<<grid, FIN_THREADS, 0, st>>>(f);
+    else if (metric == 1)
+      k_finalize_mx<1, false><<<grid, FIN_THREADS, 0, st>>>(f);
+    else
+      k_finalize_mx<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
+  }
+  else if (metric == 0)
+    k_finalize<0, false><<<grid, FIN_THREADS, 0, st>>>(f);
+  else if (metric == 1)
+    k_finalize<1, false><<<grid, FIN_THREADS, 0, st>>>(f);
+  else
+    k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
+}
+
 static int run_search(icpx_ctx* c)
 {
   c->last_local = false;
@@ -2083,20 +2132,11 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
   FinalArgs f;
   fill_final(c, f, max_dist, min_dot, use_sn, use_sn || metric == ICPX_METRIC_PLANE_TO_PLANE);
   const bool want_stat = stat && !c->stat_pending; // (what the shortcut's policy looks at)
-  // one resident round: three wavefronts per SIMD (the kernel's register budget) on every CU
-  int grid = (int)nblk(c->nq, FIN_THREADS);
-  if (grid > c->num_cus * 3)
-    grid = c->num_cus * 3;
-  if (grid > c->max_blocks)
-    grid = c->max_blocks;
+  // one resident round of the build that suits the cloud's size
+  int grid = finalize_grid(c, c->nq);
   {
     ScopedTimer tm(c, 1);
-    if (metric == 0)
-      k_finalize<0, false><<<grid, FIN_THREADS, 0, st>>>(f);
-    else if (metric == 1)
-      k_finalize<1, false><<<grid, FIN_THREADS, 0, st>>>(f);
-    else
-      k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
+    launch_finalize_sums(c, metric, f, c->nq, grid, st);
   }
   const int cert_mode = c->pass_certs ? 1 : 0;
   if (fuse_solve)
@@ -2254,17 +2294,10 @@ extern "C" int icpx_accumulate_static(icpx_ctx* c, int metric, const double T[16
   f.nq = nq;
   f.hint = hint;
   f.partials = partials;
-  int grid = (int)nblk(nq, FIN_THREADS); // (the same shape as icpx_accumulate's: same sums)
-  if (grid > c->num_cus * 3)
-    grid = c->num_cus * 3;
-  if (grid > std::min(c->max_blocks, STATIC_MAX_BLOCKS))
-    grid = std::min(c->max_blocks, STATIC_MAX_BLOCKS);
-  if (metric == 0)
-    k_finalize<0, false><<<grid, FIN_THREADS, 0, st>>>(f);
-  else if (metric == 1)
-    k_finalize<1, false><<<grid, FIN_THREADS, 0, st>>>(f);
-  else
-    k_finalize<2, false><<<grid, FIN_THREADS, 0, st>>>(f);
+  int grid = finalize_grid(c, nq); // (the same shape and build as icpx_accumulate's: same sums)
+  if (grid > STATIC_MAX_BLOCKS)
+    grid = STATIC_MAX_BLOCKS;
+  launch_finalize_sums(c, metric, f, nq, grid, st);
   // (no counters, no policy figures, and the context's certificates are left as they are)
   k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(partials, grid, sums_device, &c->d_state->done,
     nullptr, nullptr, c->d_state->T, c->d_state->cert_T, nullptr, 0, c->cap2, nullptr);

@@ -361,8 +361,104 @@ __device__ __forceinline__ void add_row(double* acc, const d3& s, const d3& t, c
   }
 }
 
+// The same moments as the Gram matrix of a 16-vector per accepted row,
+//   f = [a(3), nn(3), r, 1, sp(3), tp(3), |s - t|, 0]
+// (a = u x nn, r = (s - t).nn, with u and nn as add_row has them; a, nn, r zero for the
+// point-to-point metric): sum over rows of f f^T holds every sum add_row keeps (count = the
+// 1.1 entry, the plain sums in the row of the 1, the second moments where their factors
+// meet), and a matrix core accumulates it in FOUR accumulator registers per lane where the
+// per-lane sums take 35 (v_mfma_f64_16x16x4_f64: A[i][k] and B[k][j] one double per lane, i
+// = j = lane & 15, k = lane >> 4; D[(lane >> 4) + 4 r][lane & 15] in register r).  A rejected
+// row contributes the zero vector.
+constexpr int FEAT = 16;
+constexpr int FEAT_STRIDE = 65; // doubles per feature row in LDS: 64 queries + 1 (banks)
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int METRIC>
+__device__ __forceinline__ void row_features(double* f, const d3& s, const d3& t, const d3& n,
+  const d3& sn, const double* o)
+{
+  const d3 sp = mk(s.x - o[0], s.y - o[1], s.z - o[2]);
+  const d3 tp = mk(t.x - o[0], t.y - o[1], t.z - o[2]);
+  const d3 df = mk(s.x - t.x, s.y - t.y, s.z - t.z);
+#pragma unroll
+  for (int i = 0; i < 7; i++)
+    f[i] = 0.0;
+  f[7] = 1.0;
+  f[8] = sp.x;
+  f[9] = sp.y;
+  f[10] = sp.z;
+  f[11] = tp.x;
+  f[12] = tp.y;
+  f[13] = tp.z;
+  f[14] = sqrt(df.x * df.x + df.y * df.y + df.z * df.z);
+  f[15] = 0.0;
+  if (METRIC != 0)
+  {
+    d3 nn = n, u = sp;
+    if (METRIC == 2)
+    {
+      nn = mk(sn.x + n.x, sn.y + n.y, sn.z + n.z);
+      u = mk(sp.x + tp.x, sp.y + tp.y, sp.z + tp.z);
+    }
+    f[0] = u.y * nn.z - u.z * nn.y;
+    f[1] = u.z * nn.x - u.x * nn.z;
+    f[2] = u.x * nn.y - u.y * nn.x;
+    f[3] = nn.x;
+    f[4] = nn.y;
+    f[5] = nn.z;
+    f[6] = df.x * nn.x + df.y * nn.y + df.z * nn.z;
+  }
+}
+
+// Where sum i of the metric's layout (add_row's) sits in the Gram matrix: row * 16 + column.
+template <int METRIC>
+__device__ __forceinline__ int gram_slot(int i)
+{
+  constexpr int ONE = 7, SP = 8, TP = 11, DIST = 14, A = 0, N = 3, R = 6;
+  if (i == 0)
+    return ONE * 16 + ONE;
+  if (i == 1)
+    return ONE * 16 + DIST;
+  if (i < 5)
+    return ONE * 16 + SP + (i - 2);
+  if (METRIC == 0)
+  {
+    if (i < 8)
+      return ONE * 16 + TP + (i - 5);
+    return (SP + (i - 8) / 3) * 16 + TP + (i - 8) % 3;
+  }
+  int b = 5;
+  if (METRIC == 2)
+  {
+    if (i < 8)
+      return ONE * 16 + TP + (i - 5);
+    b = 8;
+  }
+  const int k = i - b;
+  // (xx, xy, xz, yy, yz, zz)
+  const int up_r[6] = { 0, 0, 0, 1, 1, 2 }, up_c[6] = { 0, 1, 2, 1, 2, 2 };
+  if (k < 6)
+    return (A + up_r[k]) * 16 + A + up_c[k];
+  if (k < 15)
+    return (A + (k - 6) / 3) * 16 + N + (k - 6) % 3;
+  if (k < 21)
+    return (N + up_r[k - 15]) * 16 + N + up_c[k - 15];
+  if (k < 24)
+    return (A + (k - 21)) * 16 + R;
+  return (N + (k - 24)) * 16 + R;
+}
+
 constexpr int FIN_THREADS = 256;
 
+// Two builds of the fused finalize.  k_finalize keeps the metric's sums in registers (35
+// doubles per lane at most: 168 registers, three wavefronts per SIMD); k_finalize_mx hands
+// the rows to the matrix core (four accumulator registers: 117, four wavefronts per SIMD).
+// The matrix core works off 16 x 16 products per row where the sums need 45, on the same
+// fp64 units: where every lane has a few rows to do (a million points over the whole chip)
+// the kernel is bound by its chain of dependent reads and the fourth wavefront wins (36 ->
+// 31 us); where it has dozens (sixteen million points) it is bound by arithmetic and the
+// matrix core's surplus loses (358 -> 414 us).  The host picks by the size of the cloud.
 template <int METRIC, bool ROWS>
 __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_finalize(FinalArgs a)
 {
@@ -490,6 +586,159 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))
     if (threadIdx.x < NS)
       for (int w = 0; w < FIN_THREADS / 64; w++)
         v += red[w][threadIdx.x];
+    a.partials[(int64_t)blockIdx.x * ICPX_NSUMS + threadIdx.x] = v;
+  }
+}
+
+
+template <int METRIC, bool ROWS>
+__global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_finalize_mx(FinalArgs a)
+{
+  Xf T;
+  if (!load_xf(a.T, T))
+    return; // the registration this pass belongs to has already stopped
+  constexpr int NS = SumCfg<METRIC>::N;
+  // (one region per wavefront: the rows' features on their way into the matrix core, and
+  // the wavefront's Gram matrix at the end)
+  __shared__ double feat[ROWS ? 1 : FIN_THREADS / 64][ROWS ? 1 : FEAT][ROWS ? 1 : FEAT_STRIDE];
+  v4d gram = { 0.0, 0.0, 0.0, 0.0 }, gram2 = { 0.0, 0.0, 0.0, 0.0 }; // (two chains: one waits, the other issues)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+
+  // (the trip count is the same for every lane of a wavefront: the matrix core takes all 64)
+  const int64_t stride = (int64_t)gridDim.x * FIN_THREADS;
+  for (int64_t p0 = (int64_t)blockIdx.x * FIN_THREADS + (threadIdx.x & ~63); p0 < a.nq; p0 += stride)
+  {
+    const int64_t p = min(p0 + lane, a.nq - 1);
+    const bool valid = p0 + lane < a.nq;
+    const d3 x = xform(T, a.qpos + 3 * p);
+    const int32_t hs = valid ? a.hint[p] : -1;
+    const int64_t k = a.qk[p];
+    bool accept = false;
+    float of[3] = { (float)x.x, (float)x.y, (float)x.z };
+    float cf[3] = { 0.f, 0.f, 0.f }, nf[3] = { 0.f, 0.f, 0.f }, sf[3] = { 0.f, 0.f, 0.f };
+    int32_t cell = -1;
+    double dist = 0.0;
+    if (hs >= 0)
+    {
+      d3 P0, P1, P2, pcl, cp;
+      double d2, w[3], d2b;
+      load_tri(a.tverts, hs, P0, P1, P2);
+      tri_eval(x, P0, P1, P2, pcl, d2, w);   // closest point p and vlen2 (:375)
+      dist = sqrt(d2);                        // :380
+      tri_eval(pcl, P0, P1, P2, cp, d2b, w);  // weights at p, closestPoint (:388)
+      cell = a.tid[hs];
+      const bool z0 = fabs(w[0]) < 1e-12, z1 = fabs(w[1]) < 1e-12, z2 = fabs(w[2]) < 1e-12;
+      const int count = (z0 ? 1 : 0) + (z1 ? 1 : 0) + (z2 ? 1 : 0);
+      const float* np = nullptr;
+      if (count == 0)
+        np = a.fnorm + 3 * (int64_t)cell;
+      else if (count == 1)
+      {
+        int e = z0 ? 0 : (z1 ? 1 : 2);
+        np = a.enorm + 3 * (3 * (int64_t)cell + e);
+      }
+      else if (count == 2)
+      {
+        int i = !z2 ? 2 : (!z1 ? 1 : 0); // the last weight above the tolerance (:460-466)
+        np = a.vnorm + 3 * (int64_t)a.tri[3 * (int64_t)cell + i];
+      }
+      if (np)
+      {
+        nf[0] = np[0];
+        nf[1] = np[1];
+        nf[2] = np[2];
+      }
+      cf[0] = (float)cp.x;
+      cf[1] = (float)cp.y;
+      cf[2] = (float)cp.z;
+      accept = dist < a.max_dist;
+      if (a.qsn)
+      {
+        sf[0] = a.qsn[3 * p];
+        sf[1] = a.qsn[3 * p + 1];
+        sf[2] = a.qsn[3 * p + 2];
+        if (a.rotate_sn)
+        {
+          // the normal of the moved point: T's 3x3 applied in fp64, rounded to float as the
+          // stored normals are (the reference leaves source normals unrotated)
+          const double sx = sf[0], sy = sf[1], sz = sf[2];
+          sf[0] = (float)(T.m[0] * sx + T.m[1] * sy + T.m[2] * sz);
+          sf[1] = (float)(T.m[4] * sx + T.m[5] * sy + T.m[6] * sz);
+          sf[2] = (float)(T.m[8] * sx + T.m[9] * sy + T.m[10] * sz);
+        }
+        if (a.use_sn)
+        {
+          double dn = (double)nf[0] * (double)sf[0] + (double)nf[1] * (double)sf[1] +
+            (double)nf[2] * (double)sf[2];
+          accept = accept && (dn > a.min_dot);
+        }
+      }
+    }
+    if (ROWS)
+    {
+      if (valid)
+        a.o_flag[k] = accept ? 1u : 0u;
+      if (accept)
+      {
+        for (int c = 0; c < 3; c++)
+        {
+          a.o_origin[3 * k + c] = of[c];
+          a.o_closest[3 * k + c] = cf[c];
+          a.o_normal[3 * k + c] = nf[c];
+          if (a.o_onormal)
+            a.o_onormal[3 * k + c] = sf[c];
+        }
+        a.o_cell[k] = cell;
+        a.o_dist[k] = dist;
+      }
+    }
+    else
+    {
+      double f[FEAT];
+#pragma unroll
+      for (int i = 0; i < FEAT; i++)
+        f[i] = 0.0;
+      if (accept)
+        row_features<METRIC>(f, mk((double)of[0], (double)of[1], (double)of[2]),
+          mk((double)cf[0], (double)cf[1], (double)cf[2]),
+          mk((double)nf[0], (double)nf[1], (double)nf[2]),
+          mk((double)sf[0], (double)sf[1], (double)sf[2]), a.origin);
+      // feature-major in LDS, then four rows at a time into the matrix core: lane l hands it
+      // feature l & 15 of row 4 g + (l >> 4), as the A and as the B operand
+#pragma unroll
+      for (int i = 0; i < FEAT; i++)
+        feat[wid][i][lane] = f[i];
+      __builtin_amdgcn_wave_barrier(); // (a wavefront's LDS accesses complete in order)
+#pragma unroll
+      for (int g = 0; g < 16; g += 2)
+      {
+        const double v = feat[wid][lane & 15][4 * g + (lane >> 4)];
+        const double v2 = feat[wid][lane & 15][4 * g + 4 + (lane >> 4)];
+        gram = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, gram, 0, 0, 0);
+        gram2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v2, v2, gram2, 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (ROWS)
+    return;
+
+  // fixed-shape reduction: the wavefronts' Gram matrices through LDS, the metric's sums
+  // picked out of them, one partial per block
+  double* const mine = &feat[wid][0][0];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+    mine[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = gram[r] + gram2[r];
+  __syncthreads();
+  if (threadIdx.x < ICPX_NSUMS)
+  {
+    double v = 0.0;
+    if (threadIdx.x < NS)
+    {
+      const int slot = gram_slot<METRIC>((int)threadIdx.x);
+      for (int w = 0; w < FIN_THREADS / 64; w++)
+        v += (&feat[w][0][0])[slot];
+    }
     a.partials[(int64_t)blockIdx.x * ICPX_NSUMS + threadIdx.x] = v;
   }
 }

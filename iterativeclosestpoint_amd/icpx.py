@@ -33,6 +33,7 @@ DEV_SYMBOLS = (
     "icpx_last_build_seconds", "icpx_set_group_width", "icpx_reset_hints", "icpx_set_timing",
     "icpx_get_timing", "icpx_get_pass_timings", "icpx_set_exhaustive", "icpx_set_leaf_size",
     "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local", "icpx_set_refill",
+    "icpx_set_finalize",
 )
 
 
@@ -100,6 +101,7 @@ def load():
     lib.icpx_set_leaf_size.argtypes = [vp, ci]
     lib.icpx_set_persistent.argtypes = [vp, ci]
     lib.icpx_set_refill.argtypes = [vp, ci]
+    lib.icpx_set_finalize.argtypes = [vp, ci]
     lib.icpx_set_local.argtypes = [vp, ci]
     lib.icpx_debug_dump.argtypes = [vp, ci, vp, i64]
     lib.icpx_set_timing.argtypes = [vp, ci]
@@ -225,6 +227,10 @@ class Context:
 
     def set_refill(self, lanes):
         _chk(load().icpx_set_refill(self._h, int(lanes)))
+
+    def set_finalize(self, build):
+        """0: by size; 1: sums in registers; 2: sums on the matrix core."""
+        _chk(load().icpx_set_finalize(self._h, int(build)))
 
     def set_leaf_size(self, triangles):
         _chk(load().icpx_set_leaf_size(self._h, int(triangles)))

@@ -1062,6 +1062,36 @@ def test_tree_and_far_certificates_are_sound(icpx, synth, oracle):
             assert np.all(-cert[pos][far] <= d[:, 0][far] - cap + 1e-12)
 
 
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_finalize_builds_agree(icpx, synth, small, metric):
+    """The two builds of the fused finalize (sums in registers; sums as the Gram matrix of a
+    16-vector per row on the matrix core, v_mfma_f64_16x16x4_f64) on the same rows: the same
+    count, sums equal to rounding, and both equal to the numpy restatement from the oracle's
+    rows."""
+    c, mesh = small
+    sn = synth.vertex_normals(c["source_xyz"], c["target_tri"])
+    T = synth.rigid(ry=2.0, t=(0.0, 0.01, 0.0))
+    ref = mesh.correspond(c["source_xyz"], T=T, step=1, max_dist=0.2,
+                          src_normals=sn if metric == 2 else None, grid=False)
+    got = {}
+    for build in (1, 2):
+        ctx = icpx.Context(0)
+        ctx.set_finalize(build)
+        ctx.set_target(c["target_xyz"], c["target_tri"])
+        ctx.set_source(c["source_xyz"], sn)
+        got[build] = ctx.accumulate(metric, T, step=1, max_dist=0.2)
+        again = ctx.accumulate(metric, T, step=1, max_dist=0.2)
+        assert np.array_equal(got[build], again), "sums are not reproducible run to run"
+        want = sums_from_rows(metric, ref["origin"], ref["closest"], ref["normal"],
+                              ref["origin_normal"], ctx.origin)
+        ctx.close()
+    scale = np.abs(want).max()
+    assert got[1][0] == got[2][0] == want[0] == len(ref["cell"]) > 0
+    assert np.abs(got[1] - got[2]).max() <= 1e-12 * scale
+    assert np.abs(got[1] - want).max() <= 1e-11 * scale
+    assert np.abs(got[2] - want).max() <= 1e-11 * scale
+
+
 def test_point_normals_on_device(icpx, synth, oracle):
     """icpx_point_normals against the numpy restatement of the filter's vtkPolyDataNormals
     (normalised sum of incident unit face normals): a closed surface, plus a point no triangle

@@ -51,7 +51,7 @@ def main():
 
         def timed(T, reset):
             ctx.set_local(a.local)  # the shortcut's policy starts afresh for every phase
-            ts = []
+            ts, fs = [], []
             stats_read(ctx)
             for _ in range(a.reps):
                 if reset:
@@ -60,6 +60,7 @@ def main():
                 ctx.accumulate(metric, T, 1, c["max_dist"])
                 s_ms, s_n, f_ms, f_n = ctx.get_timing()
                 ts.append(s_ms)
+                fs.append(f_ms)
             st = stats_read(ctx)
             if st is not None:
                 nq = len(c["source_xyz"]) * a.reps
@@ -69,6 +70,7 @@ def main():
                        st[5] / (nq / 64)))
                 print("   shortcut: let through on certificate %.4f of the queries, newly certified %.4f" %
                       (st[6] / nq, st[7] / nq))
+            print("   finalize %.4f ms (min of %d)" % (min(fs), len(fs)))
             return min(ts), float(np.median(ts))
         cold = timed(np.eye(4), True)
         hot0 = timed(np.eye(4), False)
