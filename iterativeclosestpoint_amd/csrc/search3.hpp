@@ -1550,6 +1550,7 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
+  __shared__ uint16_t setq[4][2048];
   const int j = threadIdx.x & 7;
   const uint32_t ngroups = nblocks * 32u;
   for (uint32_t r = block * 32u + (threadIdx.x >> 3); r < total; r += ngroups)
@@ -1639,11 +1640,22 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
       }
       continue;
     }
-    while (bits)
+    // many marked: they are listed (their places among the wavefront's 2048, in LDS) and
+    // dealt out one to a lane, so that a lane with five marked queries of its own 32 and a
+    // lane with none end up with the same two or three
     {
-      const int b = __ffs((int)bits) - 1;
-      bits &= bits - 1u;
-      const int64_t q = h * 32 + b;
+      uint32_t pos = incl - mine;
+      while (bits)
+      {
+        const int b = __ffs((int)bits) - 1;
+        bits &= bits - 1u;
+        setq[threadIdx.x >> 6][pos++] = (uint16_t)(lane * 32 + b);
+      }
+    }
+    __builtin_amdgcn_wave_barrier(); // (a wavefront's LDS accesses complete in order)
+    for (uint32_t r = (uint32_t)lane; r < marked; r += 64u)
+    {
+      const int64_t q = h0 * 32 + setq[threadIdx.x >> 6][r];
       const d3 x = xform(T, a.qpos + 3 * q);
       const int4 c0 = *reinterpret_cast<const int4*>(a.cand + q * RING3);
       const int4 c1 = *reinterpret_cast<const int4*>(a.cand + q * RING3 + 4);
@@ -1669,6 +1681,7 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
       }
       a.hint[q] = bs;
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
