@@ -115,23 +115,27 @@ __global__ void k_cert_mark(RunState* s, int mode, double cap2)
   }
 }
 
-__global__ void k_solve(RunState* s, const double* __restrict__ sums, int metric, double ox,
+// (one build per metric: with the metric a run-time value all three solvers are part of the
+// kernel, 41 KB of code of which a launch runs a quarter, straight through, once)
+template <int METRIC>
+__global__ void k_solve(RunState* s, const double* __restrict__ sums, double ox,
   double oy, double oz, int check_mean, double max_mean, const uint32_t* __restrict__ counters,
   RunRecord* rec, uint32_t seq)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0)
     return;
   const double origin[3] = { ox, oy, oz };
-  solve_and_publish(s, sums, metric, origin, check_mean, max_mean, true, counters ? counters[7] : 0u,
+  solve_and_publish(s, sums, METRIC, origin, check_mean, max_mean, true, counters ? counters[7] : 0u,
     counters ? counters[8] : 0u, rec, seq);
 }
 
 // The reduction and the solve in one launch, for a loop with nothing between them (one
 // rank): the block that finishes its sum last takes the ICPX_NSUMS totals and advances the
 // registration as k_solve does.  *ticket counts finished blocks and is left at zero.
+template <int METRIC>
 __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ partials,
   int nblocks, double* sums, uint32_t* __restrict__ counters, RunState* s, int cert_mode,
-  int metric, double ox, double oy, double oz, int check_mean, double max_mean, RunRecord* rec,
+  double ox, double oy, double oz, int check_mean, double max_mean, RunRecord* rec,
   uint32_t seq, uint32_t* ticket, double cap2)
 {
   __shared__ double tot[ICPX_NSUMS];
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
     return;
   *ticket = 0u;
   const double origin[3] = { ox, oy, oz };
-  solve_and_publish(s, tot, metric, origin, check_mean, max_mean, ran, counters ? counters[7] : 0u,
+  solve_and_publish(s, tot, METRIC, origin, check_mean, max_mean, ran, counters ? counters[7] : 0u,
     counters ? counters[8] : 0u, rec, seq);
 }
 
@@ -2144,9 +2148,18 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     // (a run's pass on one rank: the solve rides on the reduction's launch)
     const icpx_params& p = c->run_p;
     const int slot = (int)(c->run_it & 3);
-    k_reduce_solve<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, c->d_counters, c->d_state,
-      cert_mode, p.metric, c->origin[0], c->origin[1], c->origin[2], p.check_mean_distance,
-      p.max_mean_distance, c->d_rec + slot, ++c->rec_seq, c->d_ticket, c->cap2);
+    const uint32_t seq = ++c->rec_seq;
+#define ICPX_REDUCE_SOLVE(M)                                                                     \
+  k_reduce_solve<M><<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, c->d_counters,          \
+    c->d_state, cert_mode, c->origin[0], c->origin[1], c->origin[2], p.check_mean_distance,      \
+    p.max_mean_distance, c->d_rec + slot, seq, c->d_ticket, c->cap2)
+    if (p.metric == 0)
+      ICPX_REDUCE_SOLVE(0);
+    else if (p.metric == 1)
+      ICPX_REDUCE_SOLVE(1);
+    else
+      ICPX_REDUCE_SOLVE(2);
+#undef ICPX_REDUCE_SOLVE
     c->slot_seq[slot] = c->rec_seq;
     c->pass_local[slot] = c->last_local;
     c->pass_listed[slot] = c->last_listed;
@@ -2777,9 +2790,18 @@ extern "C" int icpx_run_update(icpx_ctx* c, const double* sums_device)
   hipStream_t st = c->stream;
   const icpx_params& p = c->run_p;
   const int slot = (int)(c->run_it & 3);
-  k_solve<<<1, 64, 0, st>>>(c->d_state, sums_device ? sums_device : c->d_sums, p.metric,
-    c->origin[0], c->origin[1], c->origin[2], p.check_mean_distance, p.max_mean_distance,
-    c->d_counters, c->d_rec + slot, ++c->rec_seq);
+  const uint32_t seq = ++c->rec_seq;
+#define ICPX_SOLVE(M)                                                                            \
+  k_solve<M><<<1, 64, 0, st>>>(c->d_state, sums_device ? sums_device : c->d_sums, c->origin[0],  \
+    c->origin[1], c->origin[2], p.check_mean_distance, p.max_mean_distance, c->d_counters,       \
+    c->d_rec + slot, seq)
+  if (p.metric == 0)
+    ICPX_SOLVE(0);
+  else if (p.metric == 1)
+    ICPX_SOLVE(1);
+  else
+    ICPX_SOLVE(2);
+#undef ICPX_SOLVE
   LAUNCHCHK();
   c->slot_seq[slot] = c->rec_seq;
   c->pass_local[slot] = c->last_local;

@@ -22,14 +22,6 @@
 #else
 #define ICPX_HD
 #endif
-// Work arrays that are indexed by run-time values (pivoting) would live in scratch memory
-// on the device; the device runs this code in a single thread, so they go to LDS there.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define ICPX_WS __shared__
-#else
-#define ICPX_WS
-#endif
-
 namespace icpx_core
 {
 ICPX_HD inline void swap_d(double& a, double& b)
@@ -216,43 +208,66 @@ ICPX_HD inline M3 kabsch_rotation(const M3& S)
 // that component at zero (the behaviour of Eigen::LDLT::solve the reference relies on).
 ICPX_HD inline void solve6(const double Ain[6][6], const double bin[6], double x[6])
 {
-  ICPX_WS double A[6][6];
-  ICPX_WS double y[6];
-  ICPX_WS double col[6];
-  ICPX_WS int perm[6];
+  // Every loop has a compile-time trip count and every index is a loop counter: unrolled,
+  // the work arrays stay in registers on the device (which runs this in a single thread; a
+  // run-time index, as pivoting by position would need, sends them to memory and makes
+  // every access a round trip).  The pivot's row and column are exchanged by testing each
+  // candidate position in turn.
+  double A[6][6], y[6], col[6];
+  int perm[6];
+#pragma unroll
   for (int i = 0; i < 6; i++)
+  {
+#pragma unroll
     for (int j = 0; j < 6; j++)
       A[i][j] = Ain[i][j];
-  for (int i = 0; i < 6; i++)
+    y[i] = bin[i];
     perm[i] = i;
+    col[i] = 0.0;
+  }
+#pragma unroll
   for (int k = 0; k < 6; k++)
   {
     int piv = k;
+    double big = fabs(A[k][k]);
+#pragma unroll
     for (int i = k + 1; i < 6; i++)
-      if (fabs(A[i][i]) > fabs(A[piv][piv]))
+      if (fabs(A[i][i]) > big)
+      {
+        big = fabs(A[i][i]);
         piv = i;
-    if (piv != k)
-    {
-      for (int j = 0; j < 6; j++)
-        swap_d(A[k][j], A[piv][j]);
-      for (int j = 0; j < 6; j++)
-        swap_d(A[j][k], A[j][piv]);
-      const int tp = perm[k];
-      perm[k] = perm[piv];
-      perm[piv] = tp;
-    }
+      }
+#pragma unroll
+    for (int i = k + 1; i < 6; i++)
+      if (piv == i)
+      {
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+          swap_d(A[k][j], A[i][j]);
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+          swap_d(A[j][k], A[j][i]);
+        swap_d(y[k], y[i]); // (the right-hand side goes along: y[i] = bin[perm[i]])
+        const int tp = perm[k];
+        perm[k] = perm[i];
+        perm[i] = tp;
+      }
     const double d = A[k][k];
     if (d == 0.0)
     {
+#pragma unroll
       for (int i = k + 1; i < 6; i++)
         A[i][k] = A[k][i] = 0.0;
       continue;
     }
+#pragma unroll
     for (int i = k + 1; i < 6; i++)
       col[i] = A[i][k];
+#pragma unroll
     for (int i = k + 1; i < 6; i++)
     {
       const double li = col[i] / d; // one division per row
+#pragma unroll
       for (int j = k + 1; j <= i; j++)
       {
         A[i][j] -= li * col[j];
@@ -262,19 +277,33 @@ ICPX_HD inline void solve6(const double Ain[6][6], const double bin[6], double x
       A[k][i] = 0.0;
     }
   }
+#pragma unroll
   for (int i = 0; i < 6; i++)
   {
-    y[i] = bin[perm[i]];
+#pragma unroll
     for (int j = 0; j < i; j++)
       y[i] -= A[i][j] * y[j];
   }
+#pragma unroll
   for (int i = 0; i < 6; i++)
     y[i] = (A[i][i] != 0.0) ? y[i] / A[i][i] : 0.0;
+#pragma unroll
   for (int i = 5; i >= 0; i--)
+  {
+#pragma unroll
     for (int j = i + 1; j < 6; j++)
       y[i] -= A[j][i] * y[j];
-  for (int i = 0; i < 6; i++)
-    x[perm[i]] = y[i];
+  }
+  // x[perm[i]] = y[i]
+#pragma unroll
+  for (int o = 0; o < 6; o++)
+  {
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+      v = (perm[i] == o) ? y[i] : v;
+    x[o] = v;
+  }
 }
 
 // y = R x + t in the frame shifted by `origin`  ->  row-major 4x4 in the caller's frame.
