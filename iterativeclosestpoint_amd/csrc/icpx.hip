@@ -297,6 +297,8 @@ struct icpx_ctx
   uint32_t rec_seq = 0;                      // serial number of the last solve enqueued
   uint32_t slot_seq[4] = { 0, 0, 0, 0 };     // ... and of the solve that writes each record slot
   bool run_active = false, run_done_known = false;
+  int64_t run_noted = 0; // iteration records of this run the host has looked at
+  bool noisy = false;    // the last record's mean residual is beyond the neighbour lists' reach
   double record_wait_limit = 120.0; // seconds the host waits for one iteration's record
   int64_t run_it = 0, run_step = 1;
   icpx_params run_p;
@@ -897,6 +899,7 @@ extern "C" int icpx_set_local(icpx_ctx* c, int enable)
   c->bad_streak = 0;
   c->hopeless_streak = 0;
   c->direct = false;
+  c->noisy = false;
   c->holdoff_len = 8;
   c->probation = false;
   return ICPX_OK;
@@ -952,6 +955,7 @@ extern "C" int icpx_reset_hints(icpx_ctx* c)
   c->bad_streak = 0;
   c->hopeless_streak = 0;
   c->direct = false;
+  c->noisy = false;
   c->holdoff_len = 8;
   c->probation = false;
   return ICPX_OK;
@@ -1649,12 +1653,24 @@ static int ensure_lists(icpx_ctx* c)
   return ICPX_OK;
 }
 
+// A cloud large enough for its certificates to be checked by k_certify; its passes are long
+// enough, too, for the host to stay closer behind the device (run_catch_up).
+static bool large_cloud(const icpx_ctx* c)
+{
+  return c->certify_min >= 0 && c->nq >= c->certify_min;
+}
+
 // A finished pass's figures, for the shortcut's policy (see prepare_local).
 static void note_pass(icpx_ctx* c, double n, double mean, double fallback, double listed,
   bool was_local, bool was_listed)
 {
+  // The shortcut settles a query within half the lists' radius of its triangle: with the
+  // mean residual at twice the radius it settles next to none (a noisy scan, or a cloud
+  // still far from its place), whichever kernels the pass ran.
+  if (n > 0.0)
+    c->noisy = mean > 2.0 * (c->nbr_eps > 0.f ? (double)c->nbr_eps : 0.25 * (double)c->mesh_edge);
   if (!was_local)
-    return; // a pass without the shortcut says nothing about it
+    return; // a pass without the shortcut says nothing else about it
   // The shortcut run over k_certify's list: when it settles less than half of a list of
   // some length twice in a row (a noisy cloud: its points are farther from the surface than
   // the neighbour lists reach, whatever the pose), the list goes straight to the tree
@@ -1714,6 +1730,18 @@ static int prepare_local(icpx_ctx* c, bool* use)
   {
     c->probation = true;
     c->local_holdoff--;
+    return ICPX_OK;
+  }
+  // A large cloud that stays beyond the lists' reach does without the shortcut: a pass with
+  // certificates to check hands k_certify's list straight to the tree kernels, one without
+  // is a whole tree pass (which leaves certificates).  The lists are not even built for it.
+  if (c->noisy && large_cloud(c))
+  {
+    if (!(c->use_cert && c->certs_live))
+      return ICPX_OK;
+    (void)ensure_heap(c, 64); // for short lists of leftovers (k_fallback); optional
+    c->direct = true;
+    *use = true;
     return ICPX_OK;
   }
   int rc = ensure_lists(c);
@@ -2680,6 +2708,8 @@ extern "C" int icpx_run_begin(icpx_ctx* c, const icpx_params* p)
   c->run_p = *p;
   c->run_step = landmark_step(c, p);
   c->run_it = 0;
+  c->run_noted = 0;
+  c->noisy = false;
   c->run_done_known = false;
   c->hint_valid = false; // every Update() starts cold
   c->stat_valid = false;
@@ -2719,11 +2749,8 @@ static void tally_split(icpx_ctx* c, int slot)
     c->split_pool++;
 }
 
-static int run_catch_up(icpx_ctx* c)
+static int await_record(icpx_ctx* c, int slot)
 {
-  if (c->run_it < 2)
-    return ICPX_OK;
-  const int slot = (int)((c->run_it - 2) & 3);
   // wait for that solve's serial number to show up in the pinned record (the GPU writes it
   // last); while waiting, look now and then whether the stream has drained without it
   const uint32_t want = c->slot_seq[slot];
@@ -2748,12 +2775,30 @@ static int run_catch_up(icpx_ctx* c)
     __builtin_ia32_pause();
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  const RunRecord& r = c->h_rec[slot];
-  if (r.done)
-    c->run_done_known = true;
-  note_pass(c, r.n, r.mean, (double)r.fallback, (double)r.listed, c->pass_local[slot],
-    c->pass_listed[slot]);
-  tally_split(c, slot);
+  return ICPX_OK;
+}
+
+static int run_catch_up(icpx_ctx* c)
+{
+  // Two iterations behind as a rule.  One behind for the first passes of a large cloud: each
+  // takes milliseconds, the gap the wait leaves between two of them is some ten microseconds,
+  // and what the record says (how far the cloud stays from the surface) decides which kernels
+  // the next of these, the most expensive passes of a run after the cold one, are given.
+  const int lag = (large_cloud(c) && c->since_cold <= 3) ? 1 : 2;
+  while (c->run_noted + lag <= c->run_it)
+  {
+    const int slot = (int)(c->run_noted & 3);
+    const int rc = await_record(c, slot);
+    if (rc)
+      return rc;
+    const RunRecord& r = c->h_rec[slot];
+    if (r.done)
+      c->run_done_known = true;
+    note_pass(c, r.n, r.mean, (double)r.fallback, (double)r.listed, c->pass_local[slot],
+      c->pass_listed[slot]);
+    tally_split(c, slot);
+    c->run_noted++;
+  }
   return ICPX_OK;
 }
 
