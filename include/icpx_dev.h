@@ -64,6 +64,20 @@ extern "C"
    * orders: the sums agree to rounding (1e-13 relative), not to the last bit. */
   int icpx_set_finalize(icpx_ctx* ctx, int build);
 
+  /* Lean passes of icpx_run's loop on one rank (default 1 = on).  Once a registration of a
+   * cloud below four million points has settled, every query stands on a certificate that
+   * its winner (or its small set of contenders) cannot have changed, and a pass is two
+   * launches: the fused finalize with the certificate check inside it, and the reduction
+   * with the solve.  Such a pass is tried when the last iteration record seen was of a pass
+   * that left nothing to the tree walk; if it meets a query whose certificate fails, its
+   * sums are dropped on the device and the loop repeats that pass with the search kernels.
+   * 0 = every pass runs the search kernels; 2 = a lean pass is tried whenever the last pass
+   * kept every certificate up to date, whatever the records say (for tests: lean passes
+   * then run while the cloud still moves and search many queries themselves); 3 = as 2, and
+   * every third lean pass is made to fail on the device, so that the repeat is exercised.
+   * Same results to the last bit. */
+  int icpx_set_lean(icpx_ctx* ctx, int enable);
+
   /* Search kernel selection.  0 (default): the production kernel, which screens
    * triangles with a short fp64 routine and evaluates only near-ties (within
    * 1e-9 x the largest coordinate of the minimum) with the reference's exact
@@ -82,7 +96,8 @@ extern "C"
    * that enqueued both tree kernels over the leftovers, and of a run's such passes how many
    * the wavefront walk served and how many the pooled lanes, cells the last
    * icpx_point_normals reversed for consistent winding, passes that sent the light
-   * kernel's list straight to the tree kernels} (11 x int64); 5: the shortcut's
+   * kernel's list straight to the tree kernels, lean passes enqueued, lean passes that
+   * failed and were repeated in full} (13 x int64); 5: the shortcut's
    * certificates (float per query of
    * this shard: how far the query may still move before its winner is looked at again,
    * 0 = none, negative = how far before something may come within the distance threshold;
@@ -111,7 +126,10 @@ extern "C"
   /* The same measurement pass by pass: the search kernels' milliseconds of the passes
    * timed since icpx_set_timing, oldest first (at most `cap` of them are copied);
    * *n_out = how many there are.  kind_out (optional, int32 per pass): 0 = a whole pass of
-   * the tree kernel (a cold pass when hinted_out is 0), 1 = the hinted shortcut first. */
+   * the tree kernel (a cold pass when hinted_out is 0), 1 = the hinted shortcut first, 2 = a
+   * lean pass (icpx_set_lean): its one kernel checks the certificates and makes the rows and
+   * sums, so its time is the whole pass but the reduction.  A lean pass that failed and the
+   * full pass that repeated it are two entries. */
   int icpx_get_pass_timings(icpx_ctx* ctx, double* ms_out, int32_t* kind_out,
     int32_t* hinted_out, int64_t cap, int64_t* n_out);
 

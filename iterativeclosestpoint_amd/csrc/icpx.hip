@@ -11,6 +11,7 @@
 #include "search2.hpp"
 #include "search3.hpp"
 #include "local.hpp"
+#include "lean.hpp"
 #include "state.hpp"
 #include "tables.hpp"
 #include "rows64.hpp"
@@ -21,6 +22,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -88,6 +90,7 @@ __global__ void k_set_state(RunState* s, Mat16 T, int reset)
   if (i == 0)
   {
     s->done = 0;
+    s->lean_fail = 0;
     if (reset)
     {
       s->mean = 0.0;
@@ -126,22 +129,39 @@ __global__ void k_solve(RunState* s, const double* __restrict__ sums, double ox,
     return;
   const double origin[3] = { ox, oy, oz };
   solve_and_publish(s, sums, METRIC, origin, check_mean, max_mean, true, counters ? counters[7] : 0u,
-    counters ? counters[8] : 0u, rec, seq);
+    counters ? counters[8] : 0u, counters ? counters[4] + counters[5] : 0u, rec, seq);
+}
+
+// A lean pass that failed left the registration suspended (done == 2); the host enqueues this
+// ahead of the full pass that repeats it.
+__global__ void k_resume(RunState* s)
+{
+  if (threadIdx.x == 0 && s->done == 2)
+    s->done = 0;
 }
 
 // The reduction and the solve in one launch, for a loop with nothing between them (one
 // rank): the block that finishes its sum last takes the ICPX_NSUMS totals and advances the
 // registration as k_solve does.  *ticket counts finished blocks and is left at zero.
+// lean: the pass was a lean one (k_finalize_mx<.., LEAN> alone); if it raised lean_fail its
+// sums are worth nothing: nothing is solved or recorded as brought up to date, the
+// registration is suspended (done = 2: passes enqueued behind this one return at once) and
+// the record tells the host, which repeats the pass in full.
 template <int METRIC>
 __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ partials,
   int nblocks, double* sums, uint32_t* __restrict__ counters, RunState* s, int cert_mode,
   double ox, double oy, double oz, int check_mean, double max_mean, RunRecord* rec,
-  uint32_t seq, uint32_t* ticket, double cap2)
+  uint32_t seq, uint32_t* ticket, double cap2, int lean)
 {
   __shared__ double tot[ICPX_NSUMS];
   __shared__ uint32_t last;
-  const bool ran = reduce_partials_body(partials, nblocks, sums, &s->done, counters, nullptr, s->T,
-    s->cert_T, &s->cert_ok, cert_mode, cap2, &s->cert_cap2);
+  // (every block reads the flag before it draws its ticket; the block that draws the last
+  // one clears it)
+  const bool failed = lean && *reinterpret_cast<volatile int32_t*>(&s->lean_fail) != 0;
+  // (a lean pass leaves the certificates and the transform they refer to as they are)
+  const bool ran = !failed &&
+    reduce_partials_body(partials, nblocks, sums, &s->done, counters, nullptr, s->T, s->cert_T,
+      lean ? nullptr : &s->cert_ok, cert_mode, cap2, &s->cert_cap2);
   if (threadIdx.x == 0)
   {
     __threadfence();
@@ -157,9 +177,17 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
   if (threadIdx.x != 0)
     return;
   *ticket = 0u;
+  if (failed)
+  {
+    if (s->done == 0)
+      s->done = 2;
+    s->lean_fail = 0;
+    if (counters)
+      counters[3] = 0u; // (the failed pass's count of queries it searched itself)
+  }
   const double origin[3] = { ox, oy, oz };
   solve_and_publish(s, tot, METRIC, origin, check_mean, max_mean, ran, counters ? counters[7] : 0u,
-    counters ? counters[8] : 0u, rec, seq);
+    counters ? counters[8] : 0u, counters ? counters[4] + counters[5] : 0u, rec, seq);
 }
 
 // ---- icpx_accumulate_static: scratch that lives in the code object, not on the heap ----
@@ -234,6 +262,7 @@ struct icpx_ctx
   float* d_cert = nullptr;      // per query: the shortcut's certificate (see local.hpp)
   uint32_t* d_ticket = nullptr; // k_reduce_solve's count of finished blocks (zero between launches)
   float *d_fn = nullptr, *d_en = nullptr, *d_vn = nullptr;
+  float4* d_fnpos = nullptr; // {face normal, cell id} by Morton position (the finalize kernels' read)
   // kept for the double-precision rows: fp64 face normals and the links (cells per point)
   double* d_fn64 = nullptr;
   uint32_t* d_voff = nullptr;
@@ -308,6 +337,24 @@ struct icpx_ctx
   int64_t split_wave = 0, split_pool = 0; // ... of a run, by the kernel the list's length picked
   bool last_split = false;                // the pass enqueued last was such a pass
   bool pass_split[4] = { false, false, false, false }; // ... and the run's passes, by record slot
+  // Lean passes (one rank's fused loop, clouds below certify_min): once a registration has
+  // settled, every query stands on its certificate and a pass is the fused finalize with the
+  // certificate check in it (k_finalize_mx<.., LEAN>) plus the reduction and solve: two
+  // launches instead of five.  The host cannot know that a pass will be like that (records
+  // arrive two passes late), so it is tried when the last record seen was of a pass that left
+  // nothing to the tree walk or to k_contested's lists; a lean pass that meets a query
+  // whose certificate fails suspends the registration on the device, the host sees that in
+  // the pass's record, takes the loop back to that pass and repeats it in full.
+  int use_lean = 1;
+  bool run_fused = false;     // this run is one rank's fused loop
+  bool lean_pairs_pass = false; // the pass being enqueued prepares certificates for lean passes
+  bool lean_base = false;     // the pass enqueued last left every certificate up to date the shortcut's way
+  bool clean_noted = false;   // the last record looked at was of a pass that left nothing over
+  int lean_unnoted = 0;       // lean passes enqueued whose records have not been looked at
+  int lean_holdoff = 0;       // full passes to go before the next lean one is tried
+  int lean_backoff = 4;       // ... after the next failure (doubles while failures follow one another)
+  bool pass_lean[4] = { false, false, false, false };
+  int64_t lean_passes = 0, lean_failures = 0;
   // lane-per-query kernel's tie bookkeeping, sized for q3_cap queries
   int64_t q3_cap = 0;
   int32_t* d_cand = nullptr;
@@ -532,6 +579,7 @@ static void free_target(icpx_ctx* c)
   dev_free(&c->d_tcodes);
   dev_free(&c->d_tpre);
   dev_free(&c->d_fn);
+  dev_free(&c->d_fnpos);
   dev_free(&c->d_fn64);
   dev_free(&c->d_voff);
   dev_free(&c->d_vcell);
@@ -833,10 +881,10 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
   }
   else if (what == 4)
   {
-    int64_t v[11] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
+    int64_t v[13] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
       c->nbr_total, c->certify_passes, c->split_passes, c->split_wave, c->split_pool,
-      c->last_flips, c->direct_passes };
-    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 11));
+      c->last_flips, c->direct_passes, c->lean_passes, c->lean_failures };
+    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 13));
     return ICPX_OK;
   }
   else if (what == 3 && c->d_ovf_best)
@@ -858,6 +906,11 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
   {
     src = c->d_cand; // RING3 entries per query (count = number of entries)
     bytes = sizeof(int32_t) * (size_t)std::min<int64_t>(count, c->nq * RING3);
+  }
+  else if (what == 8 && c->d_fallback)
+  {
+    src = c->d_fallback; // the last pass's list of queries left to the tree kernel
+    bytes = sizeof(uint32_t) * (size_t)std::min<int64_t>(count, c->nq);
   }
   if (!src)
     return fail(ICPX_E_INVALID, "nothing to dump");
@@ -922,6 +975,17 @@ extern "C" int icpx_set_finalize(icpx_ctx* c, int build)
   if (build < 0 || build > 2)
     return fail(ICPX_E_INVALID, "finalize build must be 0 (by size), 1 (registers) or 2 (matrix core), got %d", build);
   c->finalize_build = build;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_lean(icpx_ctx* c, int enable)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  if (enable < 0 || enable > 3)
+    return fail(ICPX_E_INVALID, "lean passes: 0 (off), 1 (on), 2 (tried at every chance) or 3 (as 2, "
+                                "every third one made to fail), got %d", enable);
+  c->use_lean = enable;
   return ICPX_OK;
 }
 
@@ -1149,6 +1213,8 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   if (!rc)
     rc = dev_alloc(&c->d_fn, 3 * nt);
   if (!rc)
+    rc = dev_alloc(&c->d_fnpos, nt);
+  if (!rc)
     rc = dev_alloc(&c->d_en, 9 * nt);
   if (!rc)
     rc = dev_alloc(&c->d_vn, 3 * nv);
@@ -1160,6 +1226,7 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   if (cell_normals)
     (void)hipMemcpyAsync(d_cn, cell_normals, sizeof(float) * 3 * nt, hipMemcpyHostToDevice, st);
   k_face_normals<<<nblk(nt, 256), 256, 0, st>>>(c->d_xyz, c->d_tri, d_cn, nt, fn64, c->d_fn);
+  k_face_by_position<<<nblk(nt, 256), 256, 0, st>>>(c->d_fn, c->d_tid, nt, c->d_fnpos);
   (void)hipMemsetAsync(voff, 0, sizeof(uint32_t) * (nv + 1), st);
   (void)hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (nv + 1), st);
   k_valence<<<nblk(3 * nt, 256), 256, 0, st>>>(c->d_tri, 3 * nt, voff);
@@ -1751,6 +1818,20 @@ static int prepare_local(icpx_ctx* c, bool* use)
   return ICPX_OK;
 }
 
+static bool finalize_on_matrix_core(const icpx_ctx* c, int64_t nq);
+static void fill_final(icpx_ctx* c, FinalArgs& f, double max_dist, double min_dot, int use_sn,
+  bool want_sn);
+static void fill_lean(icpx_ctx* c, FinalArgs& f);
+
+// Whether this run's settled passes may be lean ones (see icpx_ctx::use_lean): the fused loop
+// of one rank, a cloud whose certificates the shortcut itself checks, the default kernels.
+static bool lean_capable(const icpx_ctx* c)
+{
+  return c->use_lean && c->run_active && c->run_fused && !large_cloud(c) && c->use_local == 1 &&
+    c->use_cert && c->persistent == 4 && !c->exhaustive && pick_width(c) == 1 &&
+    finalize_on_matrix_core(c, c->nq);
+}
+
 static int run_search3(icpx_ctx* c)
 {
   const int L = c->leaf_size;
@@ -1802,7 +1883,11 @@ static int run_search3(icpx_ctx* c)
   a.cert_ok = &c->d_state->cert_ok;
   a.cert_cap2 = &c->d_state->cert_cap2;
   a.widen_max = 0.25f * c->mesh_edge;
-  a.pairs = (c->certify_min >= 0 && c->nq >= c->certify_min) ? 1 : 0;
+  // (pairs cost k_contested a few microseconds per pass where they are a thousand of a million:
+  // small clouds keep them only where lean passes, which have no k_contested, are to follow)
+  // (2: a pair only where a single winner's certificate would be next to nothing; a lean pass
+  // lets a single winner through on its certificate alone, a pair it has to weigh)
+  a.pairs = (c->certify_min >= 0 && c->nq >= c->certify_min) ? 1 : lean_capable(c) ? 2 : 0;
   a.setmask = nullptr; // (set below, once the pass's kernels are known)
   a.refill = c->refill_override > 0 ? c->refill_override : (c->hint_valid ? 40 : REFILL3);
   hipStream_t st = c->stream;
@@ -1855,6 +1940,8 @@ static int run_search3(icpx_ctx* c)
     la.work = nullptr;
     la.work_count = nullptr;
     la.segcap = 0;
+    la.pairs_to_tree = (lean_capable(c) && a.cert && c->heaps[4].built) ? 1 : 0;
+    c->lean_pairs_pass = la.pairs_to_tree != 0;
     unsigned lgrid = grid;
     bool listed = false;
     // a large cloud with certificates from the last pass: those are checked by a light
@@ -1943,8 +2030,19 @@ static int run_search3(icpx_ctx* c)
     launch_search3<2>(c, a, grid, pgrid, wgrid, mode, widep, st);
   else
     launch_search3<4>(c, a, grid, pgrid, wgrid, mode, widep, st);
+  if (use_local && c->lean_pairs_pass)
+  {
+    // certificates for what the search kernels left without one (lean.hpp)
+    FinalArgs f;
+    fill_final(c, f, 0.0, 0.0, 0, false);
+    fill_lean(c, f);
+    k_certify_rest<<<grid, 256, 0, st>>>(f);
+  }
   LAUNCHCHK();
   c->hint_valid = true;
+  // (what a lean pass can follow: the shortcut checked every certificate and whatever was
+  // searched again, here or by the tree kernels, got a new one)
+  c->lean_base = use_local && !c->last_listed && c->pass_certs && mode == 1 && widep != nullptr;
   return ICPX_OK;
 }
 
@@ -2005,6 +2103,8 @@ static int run_search(icpx_ctx* c)
   c->last_local = false;
   c->last_listed = false;
   c->last_split = false;
+  c->lean_base = false;
+  c->lean_pairs_pass = false;
   c->certs_live = c->pass_certs && c->hint_valid; // (what the last pass left)
   c->pass_certs = false;
   const int G = pick_width(c);
@@ -2116,6 +2216,7 @@ static void fill_final(icpx_ctx* c, FinalArgs& f, double max_dist,
   f.tid = c->d_tid;
   f.tri = c->d_tri;
   f.fnorm = c->d_fn;
+  f.fnpos = c->d_fnpos;
   f.enorm = c->d_en;
   f.vnorm = c->d_vn;
   f.hint = c->d_hint;
@@ -2142,6 +2243,78 @@ static int check_call(icpx_ctx* c, const double* T, int metric, int use_sn)
   return ICPX_OK;
 }
 
+static int run_catch_up(icpx_ctx* c, int lag_override = -1);
+
+// What a lean pass and k_certify_rest need beyond the finalize's arguments.
+static void fill_lean(icpx_ctx* c, FinalArgs& f)
+{
+  f.cert = c->d_cert;
+  f.cert_T = c->d_state->cert_T;
+  f.cert_ok = &c->d_state->cert_ok;
+  f.cert_cap2 = &c->d_state->cert_cap2;
+  f.cand = c->d_cand;
+  f.cand_rw = c->d_cand;
+  f.hint_rw = c->d_hint;
+  f.cap2 = c->cap2;
+  f.lean_fail = &c->d_state->lean_fail;
+  f.noff = c->d_noff;
+  f.nbr = c->d_nbr;
+  f.nbr_cap = NBR_CAP;
+  f.eps = c->nbr_eps;
+  f.scene_max = c->scene_max;
+}
+
+// A lean pass of one rank's fused loop: the certificate check and the fused sums in one
+// kernel, the reduction and the solve in the other.  Nothing on the host changes but the
+// run's position: the shortcut's policy, the pass counters and the certificates' standing
+// are those of the last full pass.
+static int enqueue_lean(icpx_ctx* c, int metric, double max_dist, double min_dot, int use_sn,
+  double* dst)
+{
+  hipStream_t st = c->stream;
+  FinalArgs f;
+  fill_final(c, f, max_dist, min_dot, use_sn, use_sn || metric == ICPX_METRIC_PLANE_TO_PLANE);
+  fill_lean(c, f);
+  f.lean_inject = (c->use_lean == 3 && c->lean_passes % 3 == 1) ? 1 : 0;
+  const int grid = finalize_grid(c, c->nq);
+  {
+    // (timed as a search pass of kind 2: the one kernel is the pass's first and last)
+    ScopedTimer tm(c, 0, true);
+    tm.kind = 2;
+    tm.hinted = 1;
+    if (metric == 0)
+      launch_ev(c, true, k_finalize_mx<0, false, true>, (unsigned)grid, FIN_THREADS, st, f);
+    else if (metric == 1)
+      launch_ev(c, true, k_finalize_mx<1, false, true>, (unsigned)grid, FIN_THREADS, st, f);
+    else
+      launch_ev(c, true, k_finalize_mx<2, false, true>, (unsigned)grid, FIN_THREADS, st, f);
+  }
+  const icpx_params& p = c->run_p;
+  const int slot = (int)(c->run_it & 3);
+  const uint32_t seq = ++c->rec_seq;
+#define ICPX_REDUCE_SOLVE(M)                                                                     \
+  k_reduce_solve<M><<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, c->d_counters,          \
+    c->d_state, 1, c->origin[0], c->origin[1], c->origin[2], p.check_mean_distance,              \
+    p.max_mean_distance, c->d_rec + slot, seq, c->d_ticket, c->cap2, 1)
+  if (p.metric == 0)
+    ICPX_REDUCE_SOLVE(0);
+  else if (p.metric == 1)
+    ICPX_REDUCE_SOLVE(1);
+  else
+    ICPX_REDUCE_SOLVE(2);
+#undef ICPX_REDUCE_SOLVE
+  LAUNCHCHK();
+  c->slot_seq[slot] = c->rec_seq;
+  c->pass_local[slot] = false;
+  c->pass_listed[slot] = false;
+  c->pass_split[slot] = false;
+  c->pass_lean[slot] = true;
+  c->run_it++;
+  c->lean_unnoted++;
+  c->lean_passes++;
+  return ICPX_OK;
+}
+
 // Search + fused sums of one pass, enqueued on the stream; the transform is the one in
 // the device state.  `stat` asks for the pass's {n, sum |s-t|} to be copied to the host
 // behind an event (for callers that do not run the device-resident loop).
@@ -2158,6 +2331,32 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     return ICPX_OK;
   }
   set_cap(c, max_dist);
+  if (fuse_solve)
+  {
+    // A lean pass when the run has settled (see icpx_ctx::use_lean); a full pass must not be
+    // enqueued behind lean ones whose records are still out (if one of them failed, this
+    // pass's bookkeeping on the host would be of a pass that never ran).
+    // (use_lean == 2, for tests: tried whatever the last record said, so that lean passes
+    // fail and are repeated while the cloud still moves)
+    bool lean = lean_capable(c) && c->lean_base && (c->clean_noted || c->use_lean >= 2) &&
+      c->lean_holdoff == 0 && c->hint_valid && c->d_cand && c->d_cert;
+    if (!lean && c->lean_unnoted > 0)
+    {
+      const int64_t it0 = c->run_it;
+      rc = run_catch_up(c, 0);
+      if (rc)
+        return rc;
+      if (c->run_done_known)
+        return ICPX_OK;
+      if (c->run_it == it0)
+        lean = lean_capable(c) && c->lean_base && (c->clean_noted || c->use_lean >= 2) &&
+          c->lean_holdoff == 0;
+    }
+    if (lean)
+      return enqueue_lean(c, metric, max_dist, min_dot, use_sn, dst);
+    if (c->lean_holdoff > 0)
+      c->lean_holdoff--;
+  }
   rc = run_search(c);
   if (rc)
     return rc;
@@ -2180,7 +2379,7 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
 #define ICPX_REDUCE_SOLVE(M)                                                                     \
   k_reduce_solve<M><<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, c->d_counters,          \
     c->d_state, cert_mode, c->origin[0], c->origin[1], c->origin[2], p.check_mean_distance,      \
-    p.max_mean_distance, c->d_rec + slot, seq, c->d_ticket, c->cap2)
+    p.max_mean_distance, c->d_rec + slot, seq, c->d_ticket, c->cap2, 0)
     if (p.metric == 0)
       ICPX_REDUCE_SOLVE(0);
     else if (p.metric == 1)
@@ -2192,6 +2391,7 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     c->pass_local[slot] = c->last_local;
     c->pass_listed[slot] = c->last_listed;
     c->pass_split[slot] = c->last_split;
+    c->pass_lean[slot] = false;
     c->run_it++;
   }
   else
@@ -2720,6 +2920,14 @@ extern "C" int icpx_run_begin(icpx_ctx* c, const icpx_params* p)
   c->direct = false;
   c->holdoff_len = 8;
   c->probation = false;
+  c->run_fused = false;
+  c->lean_base = false;
+  c->clean_noted = false;
+  c->lean_unnoted = 0;
+  c->lean_holdoff = 0;
+  c->lean_backoff = 4;
+  for (int s = 0; s < 4; s++)
+    c->pass_lean[s] = false;
   double I[16];
   for (int i = 0; i < 16; i++)
     I[i] = (i % 5 == 0) ? 1.0 : 0.0;
@@ -2778,13 +2986,16 @@ static int await_record(icpx_ctx* c, int slot)
   return ICPX_OK;
 }
 
-static int run_catch_up(icpx_ctx* c)
+static int run_catch_up(icpx_ctx* c, int lag_override)
 {
   // Two iterations behind as a rule.  One behind for the first passes of a large cloud: each
   // takes milliseconds, the gap the wait leaves between two of them is some ten microseconds,
   // and what the record says (how far the cloud stays from the surface) decides which kernels
   // the next of these, the most expensive passes of a run after the cold one, are given.
-  const int lag = (large_cloud(c) && c->since_cold <= 3) ? 1 : 2;
+  // (lag_override 0: everything enqueued so far, for a caller that must know how the lean
+  // passes still out have ended)
+  const int lag = lag_override >= 0 ? lag_override + 1
+                                    : (large_cloud(c) && c->since_cold <= 3) ? 1 : 2;
   while (c->run_noted + lag <= c->run_it)
   {
     const int slot = (int)(c->run_noted & 3);
@@ -2792,6 +3003,38 @@ static int run_catch_up(icpx_ctx* c)
     if (rc)
       return rc;
     const RunRecord& r = c->h_rec[slot];
+    if (c->pass_lean[slot] && c->lean_unnoted > 0)
+      c->lean_unnoted--;
+    if (r.done == 2)
+    {
+      // A lean pass met a query whose certificate did not hold: its sums were dropped, the
+      // registration stands where it stood before that pass, and that pass and the ones
+      // enqueued behind it (lean ones, which returned at once) count for nothing.  The loop
+      // goes back to it; the device is told to carry on, and the next passes are full ones.
+      c->lean_failures++;
+      c->run_it = c->run_noted;
+      c->lean_unnoted = 0;
+      c->lean_holdoff = c->use_lean >= 2 ? 1 : c->lean_backoff;
+      c->lean_backoff = c->lean_backoff < 32 ? 2 * c->lean_backoff : 32;
+      c->clean_noted = false;
+      k_resume<<<1, 64, 0, c->stream>>>(c->d_state);
+      LAUNCHCHK();
+      return ICPX_OK;
+    }
+    if (c->pass_lean[slot])
+      c->lean_backoff = 4;
+    {
+      static const bool trace = std::getenv("ICPX_TRACE") != nullptr; // (development aid)
+      if (trace)
+        std::fprintf(stderr, "[icpx] pass %lld %s iters %d done %d n %.0f mean %.3e fallback %u "
+                             "contested %u listed %u base %d holdoff %d\n",
+          (long long)c->run_noted, c->pass_lean[slot] ? "lean" : c->pass_local[slot] ? "local" : "tree",
+          r.iters, r.done, r.n, r.mean, r.fallback, r.contested, r.listed, (int)c->lean_base,
+          c->lean_holdoff);
+    }
+    // (the few queries that pass left to the tree kernels were given certificates by them)
+    c->clean_noted = (c->pass_lean[slot] || (c->pass_local[slot] && !c->pass_listed[slot])) &&
+      (int64_t)r.fallback + (int64_t)r.contested <= std::max<int64_t>(16, c->nq >> 13);
     if (r.done)
       c->run_done_known = true;
     note_pass(c, r.n, r.mean, (double)r.fallback, (double)r.listed, c->pass_local[slot],
@@ -2893,8 +3136,17 @@ extern "C" int icpx_run(icpx_ctx* c, const icpx_params* p, double T_out[16], int
     // one rank: nothing leaves the device until the loop is over
     rc = icpx_run_begin(c, p);
     const bool fuse = !rc && c->nq > 0; // (an empty shard has no reduction to ride on)
-    for (int it = 0; it < p->max_iterations && !rc; it++)
+    c->run_fused = fuse;
+    // (c->run_it is the run's position: a failed lean pass takes it back)
+    while (!rc && !c->run_done_known)
     {
+      if (c->run_it >= p->max_iterations)
+      {
+        if (c->lean_unnoted == 0)
+          break;
+        rc = run_catch_up(c, 0); // how did the lean passes still out end?
+        continue;
+      }
       int done = 0;
       rc = run_enqueue_impl(c, nullptr, &done, fuse);
       if (rc || done)

@@ -229,6 +229,12 @@ struct LocalArgs
   const uint32_t* work;
   const uint32_t* work_count;
   int64_t segcap;
+  // not zero: a query settled here with a single winner whose certificate comes out at next
+  // to nothing (the runner-up is a hair behind: the triangle across an edge the foot point is
+  // next to) is put on the tree kernel's list as well, which keeps winner and runner-up as a
+  // set of two under a certificate worth having (make_certificate_pair); without this such
+  // a query is searched here again on every pass, for good
+  int pairs_to_tree;
 };
 
 constexpr int LOCAL_STEPS = 16; // moves along the surface before a query is given up
@@ -385,6 +391,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         a.cert[q] = keep;
         certified = keep != 0.f;
         certset = sc && certified;
+        // (where lean passes are to follow, a single winner's certificate that is nearly
+        // used up is made anew here, or as a pair by the tree kernel, while that costs a
+        // search among hundreds: the lean passes hold every query against the certificates
+        // as the last full pass leaves them)
+        if (la.pairs_to_tree && slack > 0.f && !sc && keep < 2.f * eabs)
+          certified = false;
       }
     }
     hs = (a.use_hint && !certified) ? a.hint[q] : -1;
@@ -573,6 +585,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 
   // the certificate of a query settled with a single contender; none for any other query
   // that was looked at
+  bool to_tree = false;
   if (a.cert && active && !certified && local)
   {
     float slack = 0.f;
@@ -583,6 +596,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         fminf(eabs, 0.2f * eabs * eabs / fmaxf(dw, 1e-30f)); // (see make_certificate)
     }
     a.cert[q] = cert_encode(slack, cnt >= 2);
+    to_tree = la.pairs_to_tree && cnt == 1 && !(slack >= 2.f * eabs);
+  }
+  if (la.pairs_to_tree)
+  {
+    // (the winner found here is the tree kernel's starting bound: hint[] below)
+    const unsigned long long mp = __ballot(to_tree);
+    if (mp)
+    {
+      const int leader = __ffsll((long long)mp) - 1;
+      uint32_t base = 0;
+      if (lane == leader)
+        base = atomicAdd(&a.counters[3], (uint32_t)__popcll(mp));
+      base = __shfl(base, leader, 64);
+      if (to_tree)
+        la.fallback[base + __popcll(mp & lt)] = (uint32_t)q;
+    }
   }
 
 #ifdef ICPX_STATS

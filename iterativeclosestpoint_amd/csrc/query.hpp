@@ -21,6 +21,7 @@
 #pragma once
 #include "../../include/icpx.h"
 #include "bvh.hpp"
+#include "cert.hpp"
 #include "tri.hpp"
 #include <stdint.h>
 
@@ -264,6 +265,10 @@ struct FinalArgs
   const float* fnorm;
   const float* enorm;
   const float* vnorm;
+  // per Morton position of a triangle: {its face normal, its cell id (the int's bits)}: what
+  // nearly every row needs of the tables, in one 16-byte read that goes out together with the
+  // triangle's points instead of two reads that wait for one another behind the evaluation
+  const float4* fnpos;
   const int32_t* hint;
   double max_dist, min_dot;
   int use_sn;
@@ -278,8 +283,34 @@ struct FinalArgs
   uint32_t* o_flag;
   // partial sums, [gridDim.x][ICPX_NSUMS] (sums only)
   double* partials;
- // pinned {n, sum |s-t|, shortcut fallbacks} for the host's policy, or null
+  // a lean pass (k_finalize_mx<.., LEAN>): the certificates and what they refer to, the
+  // contender sets (RING3 per query), the winners (rewritten for queries that stand on a
+  // set), the squared distance threshold, and the flag raised when some query's certificate
+  // does not hold
+  float* cert;
+  const double* cert_T;
+  const int32_t* cert_ok;
+  const double* cert_cap2;
+  const int32_t* cand;
+  int32_t* cand_rw;
+  int32_t* hint_rw;
+  double cap2;
+  int32_t* lean_fail;
+  // ... and for k_certify_rest (lean.hpp): the neighbour lists of local.hpp (a list longer
+  // than nbr_cap was cut short), their radius, the scene's largest coordinate (tolerances)
+  const uint32_t* noff;
+  const int32_t* nbr;
+  uint32_t nbr_cap;
+  float eps;
+  float scene_max;
+  int lean_inject; // not zero: the pass fails whatever it finds (tests of the repeat)
 };
+
+// (lean.hpp) the certificate loop of a lean pass for one wavefront (queries first + lane,
+// first + stride + lane, ...): every query held against its certificate, the few winners
+// that have to be worked out written to hint[].  Called by all 64 lanes.
+__device__ __forceinline__ void lean_certify(const FinalArgs& a, const Xf& T, const Xf& Tc,
+  bool far_on, int64_t first, int64_t stride, int lane, bool& lean_bad);
 
 template <int METRIC>
 struct SumCfg
@@ -487,15 +518,20 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))
       d3 P0, P1, P2, pcl, cp;
       double d2, w[3], d2b;
       load_tri(a.tverts, hs, P0, P1, P2);
+      const float4 fr = a.fnpos[hs];
       tri_eval(x, P0, P1, P2, pcl, d2, w);   // closest point p and vlen2 (:375)
       dist = sqrt(d2);                        // :380
       tri_eval(pcl, P0, P1, P2, cp, d2b, w);  // weights at p, closestPoint (:388)
-      cell = a.tid[hs];
+      cell = __float_as_int(fr.w);
       const bool z0 = fabs(w[0]) < 1e-12, z1 = fabs(w[1]) < 1e-12, z2 = fabs(w[2]) < 1e-12;
       const int count = (z0 ? 1 : 0) + (z1 ? 1 : 0) + (z2 ? 1 : 0);
       const float* np = nullptr;
       if (count == 0)
-        np = a.fnorm + 3 * (int64_t)cell;
+      {
+        nf[0] = fr.x;
+        nf[1] = fr.y;
+        nf[2] = fr.z;
+      }
       else if (count == 1)
       {
         int e = z0 ? 0 : (z1 ? 1 : 2);
@@ -591,12 +627,29 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))
 }
 
 
-template <int METRIC, bool ROWS>
+//
+// LEAN: the whole pass in this one kernel, for a registration that has settled: nearly every
+// query is expected to stand on its certificate (lean.hpp::lean_settle says what happens to
+// each).  A query that cannot be settled there raises *lean_fail: the pass's sums are then
+// worth nothing and the host repeats the pass with the search kernels.  Rows, their order
+// and the shape of the sums are those of the plain build, so a lean pass that succeeds
+// leaves the sums the search kernels and the plain build would have left.
+template <int METRIC, bool ROWS, bool LEAN = false>
 __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_finalize_mx(FinalArgs a)
 {
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
+  Xf Tc = T;
+  bool far_on = false, lean_bad = false;
+  if (LEAN)
+  {
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+      Tc.m[i] = uniform_f64(a.cert_T[i]);
+    lean_bad = __builtin_amdgcn_readfirstlane(*a.cert_ok) == 0 || a.lean_inject != 0; // (no certificate counts)
+    far_on = a.cap2 <= uniform_f64(*a.cert_cap2) * (1.0 + 1e-12);
+  }
   constexpr int NS = SumCfg<METRIC>::N;
   // (one region per wavefront: the rows' features on their way into the matrix core, and
   // the wavefront's Gram matrix at the end)
@@ -606,6 +659,17 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(4))
 
   // (the trip count is the same for every lane of a wavefront: the matrix core takes all 64)
   const int64_t stride = (int64_t)gridDim.x * FIN_THREADS;
+  if (LEAN)
+  {
+    // A loop of its own ahead of the rows': the wavefront's queries are held against their
+    // certificates, and the few whose winner has to be worked out (lean.hpp) get it
+    // written to hint[], where the rows' loop below finds it.  (In one loop with the rows
+    // the rare paths cost every query registers: 55 us a pass instead of 37.)
+    lean_certify(a, T, Tc, far_on, (int64_t)blockIdx.x * FIN_THREADS + (threadIdx.x & ~63), stride,
+      lane, lean_bad);
+    if (__ballot(lean_bad) != 0ull && lane == 0)
+      *a.lean_fail = 1;
+  }
   for (int64_t p0 = (int64_t)blockIdx.x * FIN_THREADS + (threadIdx.x & ~63); p0 < a.nq; p0 += stride)
   {
     const int64_t p = min(p0 + lane, a.nq - 1);
@@ -623,15 +687,20 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(4))
       d3 P0, P1, P2, pcl, cp;
       double d2, w[3], d2b;
       load_tri(a.tverts, hs, P0, P1, P2);
+      const float4 fr = a.fnpos[hs];
       tri_eval(x, P0, P1, P2, pcl, d2, w);   // closest point p and vlen2 (:375)
       dist = sqrt(d2);                        // :380
       tri_eval(pcl, P0, P1, P2, cp, d2b, w);  // weights at p, closestPoint (:388)
-      cell = a.tid[hs];
+      cell = __float_as_int(fr.w);
       const bool z0 = fabs(w[0]) < 1e-12, z1 = fabs(w[1]) < 1e-12, z2 = fabs(w[2]) < 1e-12;
       const int count = (z0 ? 1 : 0) + (z1 ? 1 : 0) + (z2 ? 1 : 0);
       const float* np = nullptr;
       if (count == 0)
-        np = a.fnorm + 3 * (int64_t)cell;
+      {
+        nf[0] = fr.x;
+        nf[1] = fr.y;
+        nf[2] = fr.z;
+      }
       else if (count == 1)
       {
         int e = z0 ? 0 : (z1 ? 1 : 2);

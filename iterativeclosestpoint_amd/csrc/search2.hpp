@@ -564,7 +564,8 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
         {
           bool pair;
           nearc = make_certificate_pair(1, best, m1, m2, a.cand ? id1 : -1, INFINITY, dbox, tau,
-            eabs, a.cap2, a.pairs ? fmaxf(a.widen, 4.f * eabs) : -INFINITY, pair);
+            eabs, a.cap2,
+            a.pairs == 2 ? 2.f * eabs : a.pairs ? fmaxf(a.widen, 4.f * eabs) : -INFINITY, pair);
           if (pair && j == 0)
           {
             a.cand[q * RING3 + 0] = ring[g][0];

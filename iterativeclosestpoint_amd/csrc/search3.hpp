@@ -673,7 +673,8 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
         // more than none)
         bool pair;
         a.cert[q] = make_certificate_pair(cnt, best, sec2, sec3, sec_id, minraw, INFINITY, tau,
-          eabs, a.cap2, a.pairs ? fmaxf(widen, 4.f * eabs) : -INFINITY, pair);
+          eabs, a.cap2,
+          a.pairs == 2 ? 2.f * eabs : a.pairs ? fmaxf(widen, 4.f * eabs) : -INFINITY, pair);
         if (pair)
         {
           // the set of two, for later passes (this pass's winner is settled: the loser is

@@ -15,14 +15,15 @@ struct RunState
   double mean, n;  // of the last solved iteration
   int32_t iters;   // solved iterations (vtkICP's NumberOfIterations)
   int32_t status;  // ICPX_RUN_*
-  int32_t done;    // 1: converged / too few rows; later passes return at once
+  int32_t done;    // 1: converged / too few rows; 2: a lean pass found a query it could not
+                   // answer and the host has to repeat it in full; later passes return at once
   uint32_t fallback; // queries the shortcut left to the tree walk in the last pass
   // ---- the shortcut's certificates (local.hpp): the transform they were last brought up
   // to date for (rows 0..2), and whether they are up to date at all
   double cert_T[12];
   double cert_cap2; // the cap (squared) the far certificates were made for
   int32_t cert_ok;
-  int32_t pad_;
+  int32_t lean_fail; // raised by a lean pass (k_finalize_mx<.., LEAN>) that met such a query
 };
 struct RunRecord
 {
@@ -31,6 +32,8 @@ struct RunRecord
   uint32_t fallback;
   uint32_t seq; // the solve's serial number, stored after the rest: the host waits for it
   uint32_t listed; // queries on k_certify's list of failed certificates in that pass (0: no such list)
+  uint32_t contested; // queries that pass left to k_contested through the tie and overflow lists
+  uint32_t pad_;
 };
 // One iteration's solve and transform update in a single GPU thread: the body of the
 // loop in vtkICP::InternalUpdate after the correspondence filter (ICP/vtkICP.cxx:218-245),
@@ -38,12 +41,12 @@ struct RunRecord
 // the host finds it two iterations later by its serial number (no event, hence no marker
 // in the queue between iterations).  run: this pass ran and the registration is not over;
 // fallback_now: the pass's count of queries the shortcut left to the tree walk; listed_now:
-// the length of k_certify's list in that pass.
+// the length of k_certify's list in that pass; contested_now: its tie and overflow lists.
 // (Everything the step reads is requested at once and the record is written from
 // registers: one lane's chain of dependent reads is what this costs.)
 __device__ inline void solve_and_publish(RunState* s, const double* __restrict__ sums, int metric,
   const double* origin, int check_mean, double max_mean, bool ran, uint32_t fallback_now,
-  uint32_t listed_now, RunRecord* rec, uint32_t seq)
+  uint32_t listed_now, uint32_t contested_now, RunRecord* rec, uint32_t seq)
 {
   double Tm[16];
 #pragma unroll
@@ -96,6 +99,7 @@ __device__ inline void solve_and_publish(RunState* s, const double* __restrict__
   rec->done = done;
   rec->fallback = fallback;
   rec->listed = ran ? listed_now : 0u;
+  rec->contested = ran ? contested_now : 0u;
   __threadfence_system();
   *reinterpret_cast<volatile uint32_t*>(&rec->seq) = seq;
 }

@@ -45,6 +45,19 @@ __global__ void k_face_normals(const float* __restrict__ xyz, const int32_t* __r
   fn32[3 * c + 2] = (float)n.z;
 }
 
+// Per Morton position of a triangle: {face normal as emitted, cell id}, for the finalize
+// kernels (tid: position -> cell id, -1 - id for a degenerate triangle, which never wins).
+__global__ void k_face_by_position(const float* __restrict__ fn32, const int32_t* __restrict__ tid,
+  int64_t nt, float4* __restrict__ fnpos)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nt)
+    return;
+  const int32_t id = tid[s];
+  const int64_t c = id >= 0 ? id : -1 - (int64_t)id;
+  fnpos[s] = make_float4(fn32[3 * c], fn32[3 * c + 1], fn32[3 * c + 2], __int_as_float(id));
+}
+
 // Links (vtkPolyData::BuildLinks): cells per point as CSR.
 __global__ void k_valence(const int32_t* __restrict__ tri, int64_t n3, uint32_t* __restrict__ val)
 {

@@ -33,7 +33,7 @@ DEV_SYMBOLS = (
     "icpx_last_build_seconds", "icpx_set_group_width", "icpx_reset_hints", "icpx_set_timing",
     "icpx_get_timing", "icpx_get_pass_timings", "icpx_set_exhaustive", "icpx_set_leaf_size",
     "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local", "icpx_set_refill",
-    "icpx_set_finalize",
+    "icpx_set_finalize", "icpx_set_lean",
 )
 
 
@@ -102,6 +102,7 @@ def load():
     lib.icpx_set_persistent.argtypes = [vp, ci]
     lib.icpx_set_refill.argtypes = [vp, ci]
     lib.icpx_set_finalize.argtypes = [vp, ci]
+    lib.icpx_set_lean.argtypes = [vp, ci]
     lib.icpx_set_local.argtypes = [vp, ci]
     lib.icpx_debug_dump.argtypes = [vp, ci, vp, i64]
     lib.icpx_set_timing.argtypes = [vp, ci]
@@ -183,12 +184,13 @@ class Context:
 
     def debug_stats(self):
         """{shortcut passes, tree-only passes, neighbour-list builds, list radius}."""
-        v = np.zeros(11, np.int64)
-        _chk(load().icpx_debug_dump(self._h, 4, _p(v), 11))
+        v = np.zeros(13, np.int64)
+        _chk(load().icpx_debug_dump(self._h, 4, _p(v), 13))
         return dict(local_passes=int(v[0]), tree_passes=int(v[1]), nbr_builds=int(v[2]),
                     nbr_eps=float(v[3]) * 1e-9, nbr_total=int(v[4]), certify_passes=int(v[5]),
                     split_passes=int(v[6]), split_wave=int(v[7]), split_pool=int(v[8]),
-                    winding_flips=int(v[9]), direct_passes=int(v[10]))
+                    winding_flips=int(v[9]), direct_passes=int(v[10]),
+                    lean_passes=int(v[11]), lean_failures=int(v[12]))
 
     def debug_counters(self):
         """Counters of the last lane-per-query pass: {ties, overflows, pool position, fallbacks}."""
@@ -232,6 +234,11 @@ class Context:
         """0: by size; 1: sums in registers; 2: sums on the matrix core."""
         _chk(load().icpx_set_finalize(self._h, int(build)))
 
+    def set_lean(self, enable=True):
+        """Settled passes of icpx_run on one rank as two launches (certificate check inside the
+        fused finalize); default on; 2: tried at every chance, 3: and every third made to fail (tests).  Same results."""
+        _chk(load().icpx_set_lean(self._h, int(enable)))
+
     def set_leaf_size(self, triangles):
         _chk(load().icpx_set_leaf_size(self._h, int(triangles)))
 
@@ -254,7 +261,8 @@ class Context:
 
     def get_pass_timings(self):
         """Search-kernel milliseconds of every pass timed since set_timing, oldest first:
-        (ms float64[n], kind int32[n]: 1 = the hinted shortcut first, hinted int32[n])."""
+        (ms float64[n], kind int32[n]: 1 = the hinted shortcut first, 2 = a lean pass,
+        hinted int32[n])."""
         n = C.c_int64(0)
         _chk(load().icpx_get_pass_timings(self._h, None, None, None, 0, C.byref(n)))
         ms = np.zeros(n.value, np.float64)
