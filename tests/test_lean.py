@@ -73,3 +73,27 @@ def test_lean_pass_stops_on_mean_distance(icpx, synth):
         res.append(ctx.run(p))
     assert res[0][1] == res[1][1] and res[0][3] == res[1][3] == 1
     assert np.array_equal(res[0][0], res[1][0]) and res[0][2] == res[1][2]
+
+
+def test_lean_passes_with_distance_threshold(icpx, synth):
+    """Partial overlap with outliers and a distance threshold: queries with nothing within the
+    threshold stand on "far" certificates, which a lean pass has to let through as well."""
+    c = synth.config_c5(nu=300, nv=150, npts=150_000)
+    ctx = icpx.Context(0)
+    ctx.set_target(c["target_xyz"], c["target_tri"])
+    ctx.set_source(c["source_xyz"])
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks = 1, 40, len(c["source_xyz"])
+    p.max_distance = c["max_dist"]
+    res = {}
+    for mode in (0, 1, 2, 3):
+        ctx.set_lean(mode)
+        before = ctx.debug_stats()
+        T, it, mean, st = ctx.run(p)
+        after = ctx.debug_stats()
+        res[mode] = (T, it, mean, st, after["lean_passes"] - before["lean_passes"],
+                     after["lean_failures"] - before["lean_failures"])
+    for mode in (1, 2, 3):
+        assert np.array_equal(res[mode][0], res[0][0]) and res[mode][1:4] == res[0][1:4], (mode, res[mode][4:])
+    assert res[2][4] >= 5, res[2][4:]
+    assert res[3][5] >= 1, res[3][4:]
