@@ -64,6 +64,15 @@ extern "C"
    * orders: the sums agree to rounding (1e-13 relative), not to the last bit. */
   int icpx_set_finalize(icpx_ctx* ctx, int build);
 
+  /* Anchored passes of the device-resident loop (default 1 = on).  While a registration only
+   * jitters about its fixed point (no source point farther than one rounding allowance of
+   * the scene from where the certificates' transform has it), the passes hold the
+   * certificates against that transform and leave them as they are, instead of wearing
+   * them down by every pass's move; certificates made meanwhile are stored less twice the
+   * query's distance from there.  0 = every pass brings the certificates up to date for its
+   * own transform.  Same results. */
+  int icpx_set_anchor(icpx_ctx* ctx, int enable);
+
   /* Lean passes of icpx_run's loop on one rank (default 1 = on).  Once a registration of a
    * cloud below four million points has settled, every query stands on a certificate that
    * its winner (or its small set of contenders) cannot have changed, and a pass is two

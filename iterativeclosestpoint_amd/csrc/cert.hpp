@@ -29,6 +29,30 @@ __device__ __forceinline__ bool cert_is_set(float c)
   return c > 0.f && (__float_as_uint(c) & 1u) != 0u;
 }
 
+// Anchored passes.  While a registration only jitters about its fixed point, the certificates
+// are held against the transform of the last pass that brought them all up to date (their
+// anchor) and left as they are, instead of being worn down by every pass's move (a cloud that
+// moves by 1e-9 a pass, back and forth, uses up 4e-9 of every slack per pass: of sixteen
+// million slacks spread over a few 1e-6 that is sixteen thousand searches a pass, for good).
+// The state's words behind cert_ok say whether the coming pass is such a one ([2]).  A
+// certificate made during such a pass is good for the query's place NOW; stored less twice the
+// query's distance from where the anchor has it, it is good measured from the anchor, which is
+// how it will be checked.
+__device__ __forceinline__ bool cert_anchored(const int32_t* cert_ok)
+{
+  return cert_ok && __builtin_amdgcn_readfirstlane(cert_ok[2]) != 0;
+}
+// c: a certificate as the makers return it; adj: twice the query's distance from the anchor
+__device__ __forceinline__ float cert_rebase(float c, float adj)
+{
+  if (c == 0.f)
+    return c;
+  if (c > 0.f)
+    return cert_encode(c - adj, cert_is_set(c));
+  const float l = -c - 0.5f * adj; // (a far certificate stands while ONE move stays below it)
+  return l > 0.f ? -l : 0.f;
+}
+
 // The certificate of a finished query.  cnt: contenders (1: a single winner; 2..RING3: a set,
 // all in the ring); best: the winner's screened squared distance; sec2: lower bound of the
 // squared distance of every screened triangle that is not (or no longer) in the ring;

@@ -91,6 +91,7 @@ __global__ void k_set_state(RunState* s, Mat16 T, int reset)
   {
     s->done = 0;
     s->lean_fail = 0;
+    s->anchored = 0; // (a transform from outside: the certificates are brought up to date for it)
     if (reset)
     {
       s->mean = 0.0;
@@ -123,13 +124,26 @@ __global__ void k_cert_mark(RunState* s, int mode, double cap2)
 template <int METRIC>
 __global__ void k_solve(RunState* s, const double* __restrict__ sums, double ox,
   double oy, double oz, int check_mean, double max_mean, const uint32_t* __restrict__ counters,
-  RunRecord* rec, uint32_t seq)
+  RunRecord* rec, uint32_t seq, float src_rmax, float anchor_reach)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0)
     return;
   const double origin[3] = { ox, oy, oz };
   solve_and_publish(s, sums, METRIC, origin, check_mean, max_mean, true, counters ? counters[7] : 0u,
-    counters ? counters[8] : 0u, counters ? counters[4] + counters[5] : 0u, rec, seq);
+    counters ? counters[8] : 0u, counters ? counters[4] + counters[5] : 0u, rec, seq, src_rmax,
+    anchor_reach);
+}
+
+// Largest |v[i]| as a float's bits (*out starts at zero; a NaN or infinity ends up on top).
+__global__ void k_abs_max(const float* __restrict__ v, int64_t n, uint32_t* __restrict__ out)
+{
+  uint32_t m = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, __float_as_uint(v[i]) & 0x7fffffffu);
+  for (int k = 32; k >= 1; k >>= 1)
+    m = max(m, (uint32_t)__shfl_xor((int)m, k, 64));
+  if ((threadIdx.x & 63) == 0 && m)
+    atomicMax(out, m);
 }
 
 // A lean pass that failed left the registration suspended (done == 2); the host enqueues this
@@ -151,7 +165,7 @@ template <int METRIC>
 __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ partials,
   int nblocks, double* sums, uint32_t* __restrict__ counters, RunState* s, int cert_mode,
   double ox, double oy, double oz, int check_mean, double max_mean, RunRecord* rec,
-  uint32_t seq, uint32_t* ticket, double cap2, int lean)
+  uint32_t seq, uint32_t* ticket, double cap2, int lean, float src_rmax, float anchor_reach)
 {
   __shared__ double tot[ICPX_NSUMS];
   __shared__ uint32_t last;
@@ -187,7 +201,8 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
   }
   const double origin[3] = { ox, oy, oz };
   solve_and_publish(s, tot, METRIC, origin, check_mean, max_mean, ran, counters ? counters[7] : 0u,
-    counters ? counters[8] : 0u, counters ? counters[4] + counters[5] : 0u, rec, seq);
+    counters ? counters[8] : 0u, counters ? counters[4] + counters[5] : 0u, rec, seq, src_rmax,
+    anchor_reach);
 }
 
 // ---- icpx_accumulate_static: scratch that lives in the code object, not on the heap ----
@@ -363,6 +378,8 @@ struct icpx_ctx
   uint32_t* d_ovf_list = nullptr;
   double* d_ovf_best = nullptr;
   float scene_max = 0.f;
+  float src_max = 0.f;  // largest |coordinate| of the source points (-1: not finite)
+  int use_anchor = 1;   // anchored passes (cert.hpp)
   int exhaustive = 0;
   double build_seconds = 0.0;
   int64_t last_flips = 0; // cells the last icpx_point_normals reversed for consistent winding
@@ -978,6 +995,14 @@ extern "C" int icpx_set_finalize(icpx_ctx* c, int build)
   return ICPX_OK;
 }
 
+extern "C" int icpx_set_anchor(icpx_ctx* c, int enable)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  c->use_anchor = enable ? 1 : 0;
+  return ICPX_OK;
+}
+
 extern "C" int icpx_set_lean(icpx_ctx* c, int enable)
 {
   if (!c)
@@ -1469,7 +1494,19 @@ extern "C" int icpx_set_source(icpx_ctx* c, const float* xyz, int64_t np, const 
   }
   else
     dev_free(&c->d_srcn);
+  // (largest |coordinate|, for the reach of anchored passes: non-negative floats order as
+  // their bits do)
+  uint32_t* d_max = nullptr;
+  ALLOC(d_max, 1);
+  HIPCHK(hipMemsetAsync(d_max, 0, sizeof(uint32_t), c->stream));
+  k_abs_max<<<std::min<unsigned>(nblk(3 * np, 256), 4096u), 256, 0, c->stream>>>(c->d_src, 3 * np, d_max);
+  uint32_t bits = 0;
+  HIPCHK(hipMemcpyAsync(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  dev_free(&d_max);
+  std::memcpy(&c->src_max, &bits, sizeof(bits));
+  if (!std::isfinite(c->src_max))
+    c->src_max = -1.f; // (no bound: no anchored passes)
   c->np = np;
   c->src_version++;
   return ICPX_OK;
@@ -1718,6 +1755,20 @@ static int ensure_lists(icpx_ctx* c)
   if (c->nbr_state == 1)
     (void)ensure_heap(c, 64); // for short lists of leftovers (k_fallback); optional
   return ICPX_OK;
+}
+
+// Anchored passes (cert.hpp): the radius about the origin that holds every source point, and
+// how far a point may be from where the certificates' transform has it for a pass to leave
+// the certificates as they are: one rounding allowance of the scene (a certificate made
+// meanwhile loses twice the query's own distance from there, which a settled registration
+// keeps a hundred times smaller).
+static float anchor_rmax(const icpx_ctx* c)
+{
+  return 1.7320509f * c->src_max * 1.000001f;
+}
+static float anchor_reach(const icpx_ctx* c)
+{
+  return (c->use_anchor && c->src_max >= 0.f) ? std::fmax(c->scene_max, c->src_max) * 2.3841858e-07f : 0.f;
 }
 
 // A cloud large enough for its certificates to be checked by k_certify; its passes are long
@@ -2022,6 +2073,8 @@ static int run_search3(icpx_ctx* c)
     wide.cand = c->d_cand;
     wide.widen = a.cert ? a.widen_max : 0.f;
     wide.pairs = a.pairs;
+    wide.cert_ok = a.cert ? &c->d_state->cert_ok : nullptr;
+    wide.cert_T = c->d_state->cert_T;
     widep = &wide;
   }
   if (L == 1)
@@ -2139,6 +2192,8 @@ static int run_search(icpx_ctx* c)
     a.cand = nullptr;
     a.widen = 0.f;
     a.pairs = 0;
+    a.cert_ok = nullptr;
+    a.cert_T = nullptr;
     ScopedTimer tm(c, 0);
     switch (G)
     {
@@ -2295,7 +2350,8 @@ static int enqueue_lean(icpx_ctx* c, int metric, double max_dist, double min_dot
 #define ICPX_REDUCE_SOLVE(M)                                                                     \
   k_reduce_solve<M><<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, c->d_counters,          \
     c->d_state, 1, c->origin[0], c->origin[1], c->origin[2], p.check_mean_distance,              \
-    p.max_mean_distance, c->d_rec + slot, seq, c->d_ticket, c->cap2, 1)
+    p.max_mean_distance, c->d_rec + slot, seq, c->d_ticket, c->cap2, 1, anchor_rmax(c),         \
+    anchor_reach(c))
   if (p.metric == 0)
     ICPX_REDUCE_SOLVE(0);
   else if (p.metric == 1)
@@ -2379,7 +2435,8 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
 #define ICPX_REDUCE_SOLVE(M)                                                                     \
   k_reduce_solve<M><<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, c->d_counters,          \
     c->d_state, cert_mode, c->origin[0], c->origin[1], c->origin[2], p.check_mean_distance,      \
-    p.max_mean_distance, c->d_rec + slot, seq, c->d_ticket, c->cap2, 0)
+    p.max_mean_distance, c->d_rec + slot, seq, c->d_ticket, c->cap2, 0, anchor_rmax(c),         \
+    anchor_reach(c))
     if (p.metric == 0)
       ICPX_REDUCE_SOLVE(0);
     else if (p.metric == 1)
@@ -2523,6 +2580,8 @@ extern "C" int icpx_accumulate_static(icpx_ctx* c, int metric, const double T[16
   a.cand = nullptr;
   a.widen = 0.f;
   a.pairs = 0;
+  a.cert_ok = nullptr;
+  a.cert_T = nullptr;
   if (G == 64)
     launch_search2<64>(a, nblk(nq, 256 / 64), st);
   else
@@ -3082,7 +3141,7 @@ extern "C" int icpx_run_update(icpx_ctx* c, const double* sums_device)
 #define ICPX_SOLVE(M)                                                                            \
   k_solve<M><<<1, 64, 0, st>>>(c->d_state, sums_device ? sums_device : c->d_sums, c->origin[0],  \
     c->origin[1], c->origin[2], p.check_mean_distance, p.max_mean_distance, c->d_counters,       \
-    c->d_rec + slot, seq)
+    c->d_rec + slot, seq, anchor_rmax(c), anchor_reach(c))
   if (p.metric == 0)
     ICPX_SOLVE(0);
   else if (p.metric == 1)

@@ -205,7 +205,7 @@ __device__ __forceinline__ void certify_rest_wave(const FinalArgs& a, unsigned l
       }
     }
     if (lane == src && fresh != 0.f)
-      a.cert[p] = fresh;
+      a.cert[p] = cert_rebase_at(fresh, a.cert_ok, a.cert_T, x, a.qpos + 3 * p);
   }
 
 }

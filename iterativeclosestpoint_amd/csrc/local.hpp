@@ -348,6 +348,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   float sec2 = 0.f; // lower bound of the squared distance of every triangle outside the ring
   // (the listed queries are the ones whose certificates failed)
   const bool cert_on = a.cert && !LISTED && a.use_hint && __builtin_amdgcn_readfirstlane(okv) != 0;
+  // (cert.hpp: an anchored pass leaves standing certificates as they are)
+  const bool anchored = a.cert && cert_anchored(la.cert_ok);
   // far certificates hold for the cap they were made for, or a smaller one
   const bool far_on = cert_on && a.cap2 <= uniform_f64(capv) * (1.0 + 1e-12);
 
@@ -388,7 +390,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
       {
         const bool sc = cert_is_set(slack);
         const float keep = slack > 0.f ? cert_encode(left * 0.9999999f, sc) : -left * 0.9999999f;
-        a.cert[q] = keep;
+        if (!anchored)
+          a.cert[q] = keep;
         certified = keep != 0.f;
         certset = sc && certified;
         // (where lean passes are to follow, a single winner's certificate that is nearly
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
       slack = __builtin_amdgcn_sqrtf(sec2) * 0.999999f - dw * 1.000001f - 2.1f * (float)tau -
         fminf(eabs, 0.2f * eabs * eabs / fmaxf(dw, 1e-30f)); // (see make_certificate)
     }
-    a.cert[q] = cert_encode(slack, cnt >= 2);
+    a.cert[q] = cert_rebase_at(cert_encode(slack, cnt >= 2), la.cert_ok, la.cert_T, x, p3);
     to_tree = la.pairs_to_tree && cnt == 1 && !(slack >= 2.f * eabs);
   }
   if (la.pairs_to_tree)
@@ -731,6 +734,7 @@ __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const bool cert_on = __builtin_amdgcn_readfirstlane(okv) != 0;
   const bool far_on = cert_on && c.cap2 <= uniform_f64(capv) * (1.0 + 1e-12);
+  const bool anchored = cert_anchored(c.cert_ok); // (cert.hpp: standing certificates stay as they are)
   const int rounds = c.rounds;
   const int64_t first = (int64_t)blockIdx.x * (256 * rounds) + tid;
   uint32_t todo_bits = 0;
@@ -756,7 +760,8 @@ __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
       {
         const bool sc = cert_is_set(slack);
         const float keep = slack > 0.f ? cert_encode(left * 0.9999999f, sc) : -left * 0.9999999f;
-        c.cert[q] = keep;
+        if (!anchored)
+          c.cert[q] = keep;
         certified = keep != 0.f;
         certset = sc && certified;
       }

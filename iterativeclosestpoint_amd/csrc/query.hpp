@@ -70,6 +70,25 @@ __device__ __forceinline__ d3 xform(const Xf& T, const float* __restrict__ p)
     T.m[8] * x + T.m[9] * y + T.m[10] * z + T.m[11]);
 }
 
+// A certificate made during an anchored pass (cert.hpp), as it is stored: less twice the
+// query's distance from where the certificates' transform has it (x: the query under this
+// pass's transform, p: its point).  The transform is read here, where a search has just
+// ended: a few reads per searched query, nothing for the others.
+__device__ __forceinline__ float cert_rebase_at(float c, const int32_t* cert_ok,
+  const double* __restrict__ cert_T, const d3& x, const float* __restrict__ p)
+{
+  if (c == 0.f || !cert_anchored(cert_ok))
+    return c;
+  Xf Tc;
+#pragma unroll
+  for (int i = 0; i < 12; i++)
+    Tc.m[i] = uniform_f64(cert_T[i]);
+  const d3 xp = xform(Tc, p);
+  const double mx = x.x - xp.x, my = x.y - xp.y, mz = x.z - xp.z;
+  const float mv = __builtin_amdgcn_sqrtf(__double2float_ru(mx * mx + my * my + mz * mz)) * 1.000001f;
+  return cert_rebase(c, 2.000002f * mv + 1e-30f);
+}
+
 __device__ __forceinline__ void load_tri(
   const float* __restrict__ tverts, int64_t s, d3& P0, d3& P1, d3& P2)
 {
@@ -837,7 +856,8 @@ __device__ __forceinline__ bool reduce_partials_body(
   const int i = blockIdx.x, l = threadIdx.x;
   if (cert_ok && i == 1)
   {
-    if (cert_mode && l < 12)
+    // (an anchored pass left the certificates as they were: so stays their transform)
+    if (cert_mode && l < 12 && cert_ok[2] == 0)
       cert_T[l] = T[l];
     if (l == 0)
     {

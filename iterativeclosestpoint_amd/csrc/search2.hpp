@@ -314,6 +314,8 @@ struct Search2Args
   int32_t* cand;   // [nq][RING3] contender sets behind set certificates (or null: no sets)
   float widen;     // margin by which the walk looks beyond its bound, so that a far certificate
                    // is worth something (0 when certificates are not kept)
+  const int32_t* cert_ok; // the certificates' standing in the run's state (cert.hpp: anchored passes), or null
+  const double* cert_T;   // ... and the transform they refer to
   int pairs;       // keep a winner and a rival next to nothing behind as a set of two
 };
 
@@ -362,15 +364,18 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
   float minbox = INFINITY, lose1 = INFINITY, lose2 = INFINITY;
   int32_t lose_id = -1;
 
+  // how far behind the minimum a triangle still joins the ring: the tie tolerance; on a second
+  // walk (below) 64 rounding allowances
+  double ring_tol = 0.0;
   auto set_best = [&](double nb) {
     // older ring entries were all above the old minimum; if the new bound is
     // below it none of them can be within tolerance of the final minimum
-    const double nbound = (sqrt(nb) + tau) * (sqrt(nb) + tau);
+    const double nbound = (sqrt(nb) + ring_tol) * (sqrt(nb) + ring_tol);
     if (nbound < best)
       cnt = 0;
     best = nb;
     bound = nbound;
-    const double rw = sqrt(nb) + tau + (double)a.widen; // (boxes are turned away beyond this)
+    const double rw = sqrt(nb) + ring_tol + (double)a.widen; // (boxes are turned away beyond this)
     boundf = fminf(fmaxf(__double2float_ru(rw * rw), FLT_MIN), FLT_MAX);
   };
 
@@ -404,6 +409,40 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
     flushed = true;
   };
 
+  // A second walk where the first one's certificate comes out at next to nothing (one wavefront
+  // per query, sets kept): a noisy point's two or three nearest triangles can be within a
+  // hair of each other, the certificate of the winner, or of winner and runner-up, is then worth
+  // a pass or two, and the query is searched again for good (a settled pass of sixteen million
+  // such points searched twenty thousand of them).  The second walk takes every triangle within
+  // 64 rounding allowances of the nearest into the ring: if they are eight at most they are the
+  // query's set, and its certificate is the distance to whatever comes after them.
+  float first_cert = 0.f;
+  int32_t first_win = -1;
+  bool again = false;
+#pragma unroll 1
+  for (int attempt = 0; attempt < (G == 64 ? 2 : 1); attempt++)
+  {
+  if (attempt == 1)
+  {
+    if (!again)
+      break;
+    __builtin_amdgcn_wave_barrier(); // (ring and stack are used anew)
+    best = DBL_MAX;
+    boundf = FLT_MAX;
+    bound = DBL_MAX;
+    cnt = 0;
+    ed2 = INFINITY;
+    eid = 0x7fffffff;
+    es = -1;
+    flushed = false;
+    hs_used = -1;
+    top = 0;
+    minlb = INFINITY;
+    minbox = INFINITY;
+    lose1 = INFINITY;
+    lose2 = INFINITY;
+    lose_id = -1;
+  }
   if (active)
   {
     x = xform(T, a.qpos + 3 * q);
@@ -413,11 +452,12 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
     const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
     eabs = smax * 2.3841858e-07f * 1.0000002f; // 2^-22 of the largest coordinate, rounded up
     tau = 1e-9 * (double)smax;
+    ring_tol = attempt == 0 ? tau : fmax(tau, 64.0 * (double)eabs);
     if (a.cap2 < 1e300)
       set_best(a.cap2);
-    if (a.use_hint)
+    if (a.use_hint || attempt == 1)
     {
-      const int32_t hs = a.hint[q];
+      const int32_t hs = attempt == 0 ? a.hint[q] : first_win;
       if (hs >= 0 && a.tid[hs] >= 0)
       {
         d3 P0, P1, P2;
@@ -566,7 +606,7 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
           nearc = make_certificate_pair(1, best, m1, m2, a.cand ? id1 : -1, INFINITY, dbox, tau,
             eabs, a.cap2,
             a.pairs == 2 ? 2.f * eabs : a.pairs ? fmaxf(a.widen, 4.f * eabs) : -INFINITY, pair);
-          if (pair && j == 0)
+          if (pair && j == 0 && (attempt == 0 || nearc > first_cert))
           {
             a.cand[q * RING3 + 0] = ring[g][0];
             a.cand[q * RING3 + 1] = id1;
@@ -576,7 +616,7 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
         else
         {
           nearc = make_certificate(cnt, best, m1, INFINITY, dbox, tau, eabs, a.cap2);
-          if (nearc != 0.f && j <= cnt && j < RING3)
+          if (nearc != 0.f && j <= cnt && j < RING3 && (attempt == 0 || nearc > first_cert))
             a.cand[q * RING3 + j] = j < cnt ? ring[g][j] : -1;
         }
       }
@@ -601,12 +641,31 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
         fminf(eabs, 0.2f * eabs * eabs / fmaxf(capd, 1e-30f));
       far = (c > 0.f && c < 1e30f) ? -c : 0.f;
     }
-    if (j == 0)
+    if (attempt == 1)
     {
-      a.hint[q] = win;
-      if (a.cert)
-        a.cert[q] = have_near ? nearc : far;
+      // (the winner is the first walk's: the exact minimum of a superset of its contenders)
+      if (j == 0 && have_near && nearc > first_cert && win == first_win)
+        a.cert[q] = cert_rebase_at(nearc, a.cert_ok, a.cert_T, x, a.qpos + 3 * q);
     }
+    else
+    {
+      if (j == 0)
+      {
+        a.hint[q] = win;
+        if (a.cert)
+          a.cert[q] = cert_rebase_at(have_near ? nearc : far, a.cert_ok, a.cert_T, x, a.qpos + 3 * q);
+      }
+      if constexpr (G == 64)
+      {
+        first_cert = have_near ? nearc : 0.f;
+        first_win = win;
+        again = a.pairs != 0 && a.cert && a.cand && have_near && win >= 0 && nearc >= 0.f &&
+          nearc < 0.25f * eabs;
+      }
+    }
+  }
+  else
+    again = false;
   }
 }
 

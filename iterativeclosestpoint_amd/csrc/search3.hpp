@@ -672,9 +672,10 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
         // (a certificate that the next few moves of this size would use up is not worth
         // more than none)
         bool pair;
-        a.cert[q] = make_certificate_pair(cnt, best, sec2, sec3, sec_id, minraw, INFINITY, tau,
-          eabs, a.cap2,
-          a.pairs == 2 ? 2.f * eabs : a.pairs ? fmaxf(widen, 4.f * eabs) : -INFINITY, pair);
+        a.cert[q] = cert_rebase_at(
+          make_certificate_pair(cnt, best, sec2, sec3, sec_id, minraw, INFINITY, tau, eabs, a.cap2,
+            a.pairs == 2 ? 2.f * eabs : a.pairs ? fmaxf(widen, 4.f * eabs) : -INFINITY, pair),
+          a.cert_ok, a.cert_T, x, a.qpos + 3 * q);
         if (pair)
         {
           // the set of two, for later passes (this pass's winner is settled: the loser is
@@ -1035,6 +1036,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
   // (read-only for the whole launch and addressed uniformly: eligible for the scalar path)
   // certificates are checked here only on a whole pass (a list holds what failed the check)
   bool cert_on = false, far_on = false;
+  // (cert.hpp: an anchored pass leaves standing certificates as they are)
+  const bool anchored = cert && cert_anchored(a.cert_ok);
   if (cert && a.use_hint && !a.qlist && __builtin_amdgcn_readfirstlane(*a.cert_ok) != 0)
   {
     cert_on = true;
@@ -1088,7 +1091,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         {
           isset = cert_is_set(slack);
           const float keep = slack > 0.f ? cert_encode(left * 0.9999999f, isset) : -left * 0.9999999f;
-          cert[q] = keep;
+          if (!anchored)
+            cert[q] = keep;
           // (a set certificate worn down to nothing: the search runs after all)
           isset = isset && keep > 0.f;
           active = !(keep != 0.f);
@@ -1487,7 +1491,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     if (active && !tie && !ovf)
       a.hint[q] = (cnt == 1) ? ring[0][lane] : -1;
     if (active && cert)
-      cert[q] = make_certificate(cnt, best, sec2, minraw, INFINITY, tau, eabs, a.cap2);
+      cert[q] = cert_rebase_at(make_certificate(cnt, best, sec2, minraw, INFINITY, tau, eabs, a.cap2),
+        a.cert_ok, a.cert_T, x, a.qpos + 3 * q);
     const unsigned long long mt = __ballot(tie);
     if (mt)
     {

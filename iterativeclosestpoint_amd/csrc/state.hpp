@@ -24,6 +24,10 @@ struct RunState
   double cert_cap2; // the cap (squared) the far certificates were made for
   int32_t cert_ok;
   int32_t lean_fail; // raised by a lean pass (k_finalize_mx<.., LEAN>) that met such a query
+  // (cert.hpp: anchored passes) whether the coming pass leaves the certificates and cert_T as
+  // they are
+  int32_t anchored;
+  int32_t pad_;
 };
 struct RunRecord
 {
@@ -46,7 +50,8 @@ struct RunRecord
 // registers: one lane's chain of dependent reads is what this costs.)
 __device__ inline void solve_and_publish(RunState* s, const double* __restrict__ sums, int metric,
   const double* origin, int check_mean, double max_mean, bool ran, uint32_t fallback_now,
-  uint32_t listed_now, uint32_t contested_now, RunRecord* rec, uint32_t seq)
+  uint32_t listed_now, uint32_t contested_now, RunRecord* rec, uint32_t seq, float src_rmax = 0.f,
+  float anchor_reach = 0.f)
 {
   double Tm[16];
 #pragma unroll
@@ -77,19 +82,38 @@ __device__ inline void solve_and_publish(RunState* s, const double* __restrict__
     {
       iters++;
       s->iters = iters;
+      double Tn[16];
       for (int r = 0; r < 4; r++)
         for (int k = 0; k < 4; k++)
         {
           double acc = 0.0;
           for (int j = 0; j < 4; j++)
             acc += M[4 * r + j] * Tm[4 * j + k];
+          Tn[4 * r + k] = acc;
           s->T[4 * r + k] = acc;
         }
+      // Is the coming pass an anchored one (cert.hpp)?  It is while no source point (within
+      // src_rmax of the origin) is farther than anchor_reach from where the certificates'
+      // transform has it: |dR p + dt| <= |dR|_F |p| + |dt|.
+      double r2 = 0.0, t2 = 0.0;
+      for (int r = 0; r < 3; r++)
+      {
+        for (int k = 0; k < 3; k++)
+        {
+          const double dlt = Tn[4 * r + k] - s->cert_T[4 * r + k];
+          r2 += dlt * dlt;
+        }
+        const double dlt = Tn[4 * r + 3] - s->cert_T[4 * r + 3];
+        t2 += dlt * dlt;
+      }
+      const double reach = (sqrt(r2) * (double)src_rmax + sqrt(t2)) * 1.000001;
+      s->anchored = (s->cert_ok != 0 && anchor_reach > 0.f && reach <= (double)anchor_reach) ? 1 : 0;
     }
     if (done)
     {
       s->status = status;
       s->done = 1;
+      s->anchored = 0;
     }
   }
   rec->mean = mean;

@@ -33,7 +33,7 @@ DEV_SYMBOLS = (
     "icpx_last_build_seconds", "icpx_set_group_width", "icpx_reset_hints", "icpx_set_timing",
     "icpx_get_timing", "icpx_get_pass_timings", "icpx_set_exhaustive", "icpx_set_leaf_size",
     "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local", "icpx_set_refill",
-    "icpx_set_finalize", "icpx_set_lean",
+    "icpx_set_finalize", "icpx_set_lean", "icpx_set_anchor",
 )
 
 
@@ -103,6 +103,7 @@ def load():
     lib.icpx_set_refill.argtypes = [vp, ci]
     lib.icpx_set_finalize.argtypes = [vp, ci]
     lib.icpx_set_lean.argtypes = [vp, ci]
+    lib.icpx_set_anchor.argtypes = [vp, ci]
     lib.icpx_set_local.argtypes = [vp, ci]
     lib.icpx_debug_dump.argtypes = [vp, ci, vp, i64]
     lib.icpx_set_timing.argtypes = [vp, ci]
@@ -233,6 +234,12 @@ class Context:
     def set_finalize(self, build):
         """0: by size; 1: sums in registers; 2: sums on the matrix core."""
         _chk(load().icpx_set_finalize(self._h, int(build)))
+
+    def set_anchor(self, enable=True):
+        """Settled passes of the device-resident loop leave the certificates as they are
+        (held against the transform of the last pass that brought them up to date); default
+        on.  Same results."""
+        _chk(load().icpx_set_anchor(self._h, int(bool(enable))))
 
     def set_lean(self, enable=True):
         """Settled passes of icpx_run on one rank as two launches (certificate check inside the
