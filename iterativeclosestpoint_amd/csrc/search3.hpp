@@ -1007,6 +1007,17 @@ typedef __attribute__((address_space(4))) const vec4f cfloat4;
 #endif
 constexpr int PENDW = 16; // queue slots per lane (a power of two)
 
+// A queued lower bound lb <= ref as 16 bits, and back (the value returned is never above lb).
+__device__ __forceinline__ uint16_t pend_encode(float lb, float ref)
+{
+  const uint32_t b = __float_as_uint(fmaxf(ref - lb, 0.f)) + 0xffffu; // (ref - lb rounded up)
+  return (uint16_t)(b >> 16);
+}
+__device__ __forceinline__ float pend_decode(uint16_t h, float ref)
+{
+  return fmaxf(ref - __uint_as_float((uint32_t)h << 16), 0.f) * 0.9999997f;
+}
+
 __device__ __forceinline__ uint32_t uni32(uint32_t v)
 {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
@@ -1023,7 +1034,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     return; // the registration this pass belongs to has already stopped
   __shared__ int32_t ring[RING3][64];
   __shared__ int32_t pend_s[PENDW][64];
-  __shared__ uint16_t pend_lb[PENDW][64]; // the lower bound's upper half (rounded towards zero)
+  // The entries' lower bounds, 16 bits each (LDS is what limits the wavefronts per CU): how far
+  // the bound is BELOW the lane's reference `pref` (its pruning bound when the queue was last
+  // weeded or empty), the float's upper half rounded up.  What decides whether an entry is
+  // weeded is its distance from the pruning bound, and that is what these bits resolve: the
+  // upper half of the bound itself is good to 1/256 of the bound, and a query dozens of
+  // triangle widths off the surface has dozens of triangles that close to its bound, each of
+  // which then cost an fp64 screen.
+  __shared__ uint16_t pend_lb[PENDW][64];
   __shared__ uint32_t stk[64];
   const int lane = threadIdx.x;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -1123,6 +1141,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     int cnt = 0, npend = 0; // queue: slots 0 .. npend-1 of this lane's column, in no order
     int pick = -1;          // after purge(): the slot of the queued triangle with the smallest bound
     int32_t hs_used = -1;
+    float pref = 0.f; // reference of the queued bounds (pend_lb)
 
     auto retighten = [&]() {
       // (the hardware's square root is within one unit in the last place: the factors
@@ -1159,14 +1178,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         if (i < npend)
         {
           const int32_t s = pend_s[i][lane];
-          const uint16_t h = pend_lb[i][lane];
-          const float lbq = __uint_as_float((uint32_t)h << 16);
+          const float lbq = pend_decode(pend_lb[i][lane], pref);
           if (lbq > prunef)
             sec2 = fminf(sec2, lbq); // dropped against the tighter bound: at least that far
           else
           {
             pend_s[w][lane] = s;
-            pend_lb[w][lane] = h;
+            pend_lb[w][lane] = pend_encode(lbq, prunef); // (against the new reference)
             if (lbq < mlb)
             {
               mlb = lbq;
@@ -1177,6 +1195,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         }
       }
       npend = w;
+      pref = prunef;
     };
     // The picked triangle is screened (straight after purge(): it is still in the race), the
     // last entry takes its slot.  Most promising first: the bound it leaves behind turns most
@@ -1438,8 +1457,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
                 sec2 = fminf(sec2, lb); // turned away: at least this far
               if (want && lb <= prunef && (int32_t)(s0 + t) != hs_used)
               {
+                if (npend == 0)
+                  pref = prunef;
                 pend_s[npend][lane] = (int32_t)(s0 + t);
-                pend_lb[npend][lane] = (uint16_t)(__float_as_uint(lb) >> 16);
+                pend_lb[npend][lane] = pend_encode(lb, pref);
                 npend++;
               }
             }
