@@ -273,6 +273,8 @@ struct icpx_ctx
   float* d_tverts = nullptr;
   int32_t* d_tid = nullptr;
   uint64_t* d_tcodes = nullptr; // sorted Morton codes of the triangles
+  uint32_t* d_tcell = nullptr;  // first position per leading tcell_bits bits of a code (k_code_cells)
+  int tcell_bits = 0;
   float4* d_tpre = nullptr;     // per-triangle plane bounds
   float* d_cert = nullptr;      // per query: the shortcut's certificate (see local.hpp)
   uint32_t* d_ticket = nullptr; // k_reduce_solve's count of finished blocks (zero between launches)
@@ -594,6 +596,7 @@ static void free_target(icpx_ctx* c)
   dev_free(&c->d_tverts);
   dev_free(&c->d_tid);
   dev_free(&c->d_tcodes);
+  dev_free(&c->d_tcell);
   dev_free(&c->d_tpre);
   dev_free(&c->d_fn);
   dev_free(&c->d_fnpos);
@@ -1202,6 +1205,18 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   if (e == hipSuccess && !rc)
     e = hipMemcpyAsync(
       c->d_tcodes, which ? k1 : k0, sizeof(uint64_t) * nt, hipMemcpyDeviceToDevice, st);
+  // (about two cells per triangle, 2^24 at most: 64 MB)
+  int cbits = 3;
+  while (cbits < 24 && ((int64_t)1 << cbits) < 2 * nt)
+    cbits += 3; // (whole levels of the octree the codes spell out)
+  c->tcell_bits = cbits;
+  if (e == hipSuccess && !rc)
+    rc = dev_alloc(&c->d_tcell, ((int64_t)1 << cbits) + 1);
+  if (e == hipSuccess && !rc)
+  {
+    k_code_cells<<<nblk(((int64_t)1 << cbits) + 1, 256), 256, 0, st>>>(c->d_tcodes, nt, cbits, c->d_tcell);
+    e = hipGetLastError();
+  }
   const hipError_t es = hipStreamSynchronize(st); // (the sort's buffers are in use until here)
   if (e == hipSuccess)
     e = es;
@@ -1919,6 +1934,8 @@ static int run_search3(icpx_ctx* c)
   a.use_hint = c->hint_valid ? 1 : 0;
   a.scene_max = c->scene_max;
   a.tcodes = c->d_tcodes;
+  a.tcell = c->d_tcell;
+  a.tcell_bits = c->tcell_bits;
   a.box = c->box;
   a.cand = c->d_cand;
   a.tie_list = c->d_tie_list;

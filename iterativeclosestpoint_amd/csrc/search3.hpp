@@ -113,6 +113,27 @@ __global__ void k_bin_level(int k, float* __restrict__ nodes)
 // From these a query gets a lower bound of its distance to the triangle that, unlike a
 // box's, does not loosen when the triangle is slanted:
 // (distance to the plane)^2 + (in-plane distance to the circle)^2.
+// cell[c] = first position of the sorted codes whose code is not below c << (63 - bits), for
+// every prefix c of `bits` bits (and cell[1 << bits] = nt).
+__global__ void k_code_cells(const uint64_t* __restrict__ codes, int64_t nt, int bits,
+  uint32_t* __restrict__ cell)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > ((int64_t)1 << bits))
+    return;
+  const uint64_t key = (uint64_t)c << (63 - bits);
+  int64_t lo = 0, hi = nt;
+  while (lo < hi)
+  {
+    const int64_t mid = (lo + hi) >> 1;
+    if (codes[mid] < key)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  cell[c] = (c == ((int64_t)1 << bits)) ? (uint32_t)nt : (uint32_t)lo;
+}
+
 __global__ void k_tri_bounds(const float* __restrict__ tverts, const int32_t* __restrict__ tid,
   int64_t nt, int64_t npad, float4* __restrict__ pre)
 {
@@ -248,6 +269,11 @@ struct Search3Args
   int use_hint;
   float scene_max;
   const uint64_t* tcodes; // Morton codes of the triangles in sorted order (cold-start seed), or null
+  // ... and, by the codes' leading tcell_bits bits, the first position whose code is not below
+  // that prefix (k_code_cells): one read where the search by halves takes twenty, one after
+  // the other, each lane its own; null: search
+  const uint32_t* tcell;
+  int tcell_bits;
   Box3 box;
   // contested queries
   int32_t* cand;        // [nq][RING3]
@@ -1255,6 +1281,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         // the nearest centroid gives the first bound
         const uint64_t code = morton63(xf, yf, zf, a.box.lo, a.box.inv);
         int64_t lo = 0, hi = a.nt; // first position with tcodes[pos] >= code
+        if (a.tcell)
+        {
+          // (the search by halves within the code's cell: a few triangles, not all of them)
+          const uint64_t cl = code >> (63 - a.tcell_bits);
+          lo = (int64_t)a.tcell[cl];
+          hi = (int64_t)a.tcell[cl + 1];
+        }
         while (lo < hi)
         {
           const int64_t mid = (lo + hi) >> 1;

@@ -70,6 +70,10 @@ def main():
                        st[5] / (nq / 64)))
                 print("   shortcut: let through on certificate %.4f of the queries, newly certified %.4f" %
                       (st[6] / nq, st[7] / nq))
+                print("   wavefront walk, per wavefront: node steps %.1f  leaves entered %.1f  past the slab %.1f  "
+                      "triangle tests %.1f  screen rounds %.1f + %.1f" %
+                      (st[0] / (nq / 64), st[1] / (nq / 64), st[7] / (nq / 64), st[6] / (nq / 64),
+                       st[4] / (nq / 64), st[5] / (nq / 64)))
             print("   finalize %.4f ms (min of %d)" % (min(fs), len(fs)))
             return min(ts), float(np.median(ts))
         cold = timed(np.eye(4), True)
