@@ -537,12 +537,10 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))
       d3 P0, P1, P2, pcl, cp;
       double d2, w[3], d2b;
       load_tri(a.tverts, hs, P0, P1, P2);
+      const float4 fr = a.fnpos[hs]; // (with the triangle: the read does not wait behind the evaluations)
       tri_eval(x, P0, P1, P2, pcl, d2, w);   // closest point p and vlen2 (:375)
       dist = sqrt(d2);                        // :380
       tri_eval(pcl, P0, P1, P2, cp, d2b, w);  // weights at p, closestPoint (:388)
-      // (read here, not with the triangle: this build is at its register limit, and four more
-      // registers live across the evaluations spill, which costs a kernel more than the wait)
-      const float4 fr = a.fnpos[hs];
       cell = __float_as_int(fr.w);
       const bool z0 = fabs(w[0]) < 1e-12, z1 = fabs(w[1]) < 1e-12, z2 = fabs(w[2]) < 1e-12;
       const int count = (z0 ? 1 : 0) + (z1 ? 1 : 0) + (z2 ? 1 : 0);
