@@ -233,63 +233,126 @@ __global__ __launch_bounds__(256) void k_certify_rest(FinalArgs a)
   certify_rest_wave(a, need, p, lane, x, hs);
 }
 
-__device__ __forceinline__ void lean_settle(const FinalArgs& a, const Xf& T, const Xf& Tc,
-  bool far_on, int64_t p, int lane, bool valid, const float* q3, float slack, const int4& c0,
-  bool& lean_bad)
+// The queries of a wavefront that stand on sets, weighed together once the certificate loop is
+// through (list: the queries, in LDS).  Weighed where they are met, a lane at a time, each costs its wavefront two dependent
+// reads and two screens while the other 63 lanes wait, and the wavefront with three or four of
+// them among its queries is what the whole kernel waits for (44 us a pass instead of 31 for
+// the rows alone); here every member of every listed set has a lane of its own, so that all of
+// them together are one read and one screen long.  A set of two: the members' screened
+// distances; farther apart than the tie tolerance, the nearer one wins, as it does for a
+// search that ends with one contender; else both are evaluated exactly, as k_contested does.
+// A larger set is left to one lane (lean_weigh).
+__device__ __forceinline__ void lean_weigh_list(const FinalArgs& a, const Xf& T, const int32_t* list,
+  int nset, int lane)
 {
-  const d3 x = xform(T, q3);
-  bool stands = false;
-  if (slack > 0.f || (slack < 0.f && far_on))
+  const int k = lane & 1;
+  for (int e0 = 0; e0 < nset; e0 += 32)
   {
-    // the move since the anchor (k_search_local's arithmetic)
-    const d3 xp = xform(Tc, q3);
-    const double mx = x.x - xp.x, my = x.y - xp.y, mz = x.z - xp.z;
-    const float m2 = __double2float_ru(mx * mx + my * my + mz * mz);
-    const float mv = __builtin_amdgcn_sqrtf(m2) * 1.000001f;
-    const float left = slack > 0.f ? slack - 2.000001f * mv - 1e-30f
-                                   : -slack - 1.000001f * mv - 1e-30f;
-    stands = left > 0.f;
+    const int e = e0 + (lane >> 1);
+    const bool on = e < nset;
+    const int64_t p = on ? list[e] : 0;
+    // (the set's first members are read here, by the few queries that stand on sets: read
+    // with the certificates, 16 bytes of every query's, they cost the pass a third of its time)
+    const int4 c0 = on ? *reinterpret_cast<const int4*>(a.cand + p * RING3) : make_int4(-1, -1, -1, -1);
+    const int4 ent = make_int4(0, c0.x, c0.y, c0.z >= 0 ? 1 : 0);
+    const bool two = on && ent.w == 0;
+    const int32_t m = k ? ent.z : ent.y;
+    d3 x = mk(0.0, 0.0, 0.0), P0 = x, P1 = x, P2 = x;
+    double d = INFINITY;
+    if (two)
+    {
+      x = xform(T, a.qpos + 3 * p);
+      load_tri(a.tverts, m, P0, P1, P2);
+      d = tri_d2_screen(x, P0, P1, P2);
+    }
+    const double dp = __shfl_xor(d, 1, 64); // (the partner lane's member)
+    bool tie = false;
+    if (two)
+    {
+      const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
+        fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
+      const double rb = sqrt(fmin(d, dp)) + 1e-9 * (double)smax;
+      tie = !(fmax(d, dp) > rb * rb);
+      if (!tie && k == 0)
+        a.hint_rw[p] = d < dp ? ent.y : ent.z;
+    }
+    if (__ballot(tie) != 0ull)
+    {
+      double dd = INFINITY;
+      int32_t id = 0x7fffffff;
+      if (tie)
+      {
+        d3 cp;
+        double w[3], de;
+        if (tri_eval(x, P0, P1, P2, cp, de, w))
+        {
+          dd = de;
+          id = a.tid[m];
+        }
+      }
+      const double ddp = __shfl_xor(dd, 1, 64);
+      const int32_t idp = __shfl_xor(id, 1, 64);
+      if (tie && k == 0)
+      {
+        // (members in their order in the set: the first, then the second if it is better)
+        int32_t bs = dd < INFINITY ? ent.y : -1;
+        if (ddp < INFINITY && (bs < 0 || better(ddp, idp, dd, id)))
+          bs = ent.z;
+        a.hint_rw[p] = bs;
+      }
+    }
+    if (on && ent.w != 0 && k == 0)
+      (void)lean_weigh(a, p, c0, xform(T, a.qpos + 3 * p));
   }
-  const bool isset = stands && cert_is_set(slack);
-  lean_bad = lean_bad || (valid && !stands);
-  if (isset)
-    (void)lean_weigh(a, p, c0, x);
 }
 
-// The certificate loop of a lean pass for one wavefront: its queries p0 + lane, p0 + stride +
-// lane, ... taken four rounds at a time, the rounds' reads (point, certificate, first
-// members of the set) requested together: a round is a read and a few dozen instructions,
-// and one after the other the reads' waits would be all this loop costs.
+// The certificate loop of a lean pass for one wavefront: its queries first + lane, first +
+// stride + lane, ...: each held against its certificate (k_search_local's arithmetic, the
+// anchor's transform Tc); the ones that stand on sets listed for lean_weigh_list (list: room
+// for LEAN_LIST entries in LDS, this wavefront's own).
+constexpr int LEAN_LIST = 1024;
 __device__ __forceinline__ void lean_certify(const FinalArgs& a, const Xf& T, const Xf& Tc,
-  bool far_on, int64_t first, int64_t stride, int lane, bool& lean_bad)
+  bool far_on, int64_t first, int64_t stride, int lane, int32_t* list, bool& lean_bad)
 {
-  constexpr int B = 1;
-  for (int64_t p0 = first; p0 < a.nq; p0 += B * stride)
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int nset = 0;
+  for (int64_t p0 = first; p0 < a.nq; p0 += stride)
   {
-    float q[B][3], sl[B];
-    int4 c0[B];
-    int64_t pp[B];
-    bool val[B];
-#pragma unroll
-    for (int b = 0; b < B; b++)
+    const bool valid = p0 + lane < a.nq;
+    const int64_t p = min(p0 + lane, a.nq - 1);
+    const float q3[3] = { a.qpos[3 * p], a.qpos[3 * p + 1], a.qpos[3 * p + 2] };
+    const float slack = valid ? a.cert[p] : 0.f;
+    bool stands = false;
+    if (slack > 0.f || (slack < 0.f && far_on))
     {
-      const int64_t pb = p0 + b * stride;
-      val[b] = pb + lane < a.nq;
-      pp[b] = min(pb + lane, a.nq - 1);
-      q[b][0] = a.qpos[3 * pp[b]];
-      q[b][1] = a.qpos[3 * pp[b] + 1];
-      q[b][2] = a.qpos[3 * pp[b] + 2];
-      sl[b] = a.cert[pp[b]];
-      // (the first members of the query's set, if it stands on one: read here, with the
-      // certificate, whether it does or not: 16 bytes per query that save the queries on
-      // sets a wait of their own)
-      c0[b] = *reinterpret_cast<const int4*>(a.cand + pp[b] * RING3);
+      // the move since the anchor
+      const d3 x = xform(T, q3), xp = xform(Tc, q3);
+      const double mx = x.x - xp.x, my = x.y - xp.y, mz = x.z - xp.z;
+      const float m2 = __double2float_ru(mx * mx + my * my + mz * mz);
+      const float mv = __builtin_amdgcn_sqrtf(m2) * 1.000001f;
+      const float left = slack > 0.f ? slack - 2.000001f * mv - 1e-30f
+                                     : -slack - 1.000001f * mv - 1e-30f;
+      stands = left > 0.f;
     }
-#pragma unroll
-    for (int b = 0; b < B; b++)
-      if (p0 + b * stride < a.nq)
-        lean_settle(a, T, Tc, far_on, pp[b], lane, val[b], q[b], val[b] ? sl[b] : 0.f, c0[b], lean_bad);
+    lean_bad = lean_bad || (valid && !stands);
+    const bool isset = stands && cert_is_set(slack);
+    const unsigned long long ms = __ballot(isset);
+    if (ms)
+    {
+      const int slot = nset + __popcll(ms & lt);
+      if (isset)
+      {
+        if (slot < LEAN_LIST)
+          list[slot] = (int32_t)p;
+        else // (no room: weighed on the spot)
+          (void)lean_weigh(a, p, *reinterpret_cast<const int4*>(a.cand + p * RING3), xform(T, q3));
+      }
+      nset = min(nset + __popcll(ms), LEAN_LIST);
+    }
   }
+  __builtin_amdgcn_wave_barrier(); // (a wavefront's LDS accesses complete in order)
+  lean_weigh_list(a, T, list, nset, lane);
+  __builtin_amdgcn_wave_barrier();
 }
 
 } // namespace icpx

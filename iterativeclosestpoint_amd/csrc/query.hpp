@@ -329,7 +329,7 @@ struct FinalArgs
 // first + stride + lane, ...): every query held against its certificate, the few winners
 // that have to be worked out written to hint[].  Called by all 64 lanes.
 __device__ __forceinline__ void lean_certify(const FinalArgs& a, const Xf& T, const Xf& Tc,
-  bool far_on, int64_t first, int64_t stride, int lane, bool& lean_bad);
+  bool far_on, int64_t first, int64_t stride, int lane, int32_t* list, bool& lean_bad);
 
 template <int METRIC>
 struct SumCfg
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     // written to hint[], where the rows' loop below finds it.  (In one loop with the rows
     // the rare paths cost every query registers: 55 us a pass instead of 37.)
     lean_certify(a, T, Tc, far_on, (int64_t)blockIdx.x * FIN_THREADS + (threadIdx.x & ~63), stride,
-      lane, lean_bad);
+      lane, reinterpret_cast<int32_t*>(&feat[wid][0][0]), lean_bad);
     if (__ballot(lean_bad) != 0ull && lane == 0)
       *a.lean_fail = 1;
   }
