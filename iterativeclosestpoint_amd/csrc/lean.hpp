@@ -9,8 +9,9 @@
 // those of that last full pass (their anchor), so the jitter does not wear them down pass
 // after pass as the search kernels' write-back would.
 //   - the certificate stands, a single winner: the winner is last pass's (hint[]);
-//   - it stands, a set of contenders (cand[]): they are weighed by exact evaluation as
-//     k_contested weighs them, the winner goes to hint[];
+//   - it stands, a set of contenders (cand[]): they are weighed again (lean_weigh_list: a set
+//     of two by its members' screened distances, a tie or a larger set by exact evaluation as
+//     k_contested does it), the winner goes to hint[];
 //   - "nothing within the distance threshold" stands: no row;
 //   - no certificate, or it does not reach: the pass has failed (lean_bad): the host repeats
 //     it with the search kernels, which give the query a new certificate.  The full passes of
@@ -27,56 +28,52 @@ namespace icpx
 __device__ __forceinline__ int32_t lean_weigh(const FinalArgs& a, int64_t p, const int4& c0,
   const d3& x)
 {
+  // The winner is the one k_contested's exact evaluation of all members would name.  A set of
+  // two is screened first: if the screened distances are farther apart than the tie tolerance
+  // the nearer one is the winner, as it is for a search that ends with one contender; only a
+  // real tie, or a larger set, is evaluated exactly.
+  double bd2 = INFINITY;
+  int32_t bid = 0x7fffffff, bs = -1;
+  bool decided = false;
+  if (c0.x >= 0 && c0.y >= 0 && c0.z < 0)
   {
-    // The set's members weighed: the winner is the one k_contested's exact evaluation of all
-    // of them would name.  A set of two (a winner and the triangle across the edge its foot
-    // point is next to; a foot point on an edge) is screened first: if the screened distances
-    // are farther apart than the tie tolerance the nearer one is the winner, as it is for a
-    // search that ends with one contender; only a real tie is evaluated exactly.
-    double bd2 = INFINITY;
-    int32_t bid = 0x7fffffff, bs = -1;
-    bool decided = false;
-    if (c0.x >= 0 && c0.y >= 0 && c0.z < 0)
+    d3 A0, A1, A2, B0, B1, B2;
+    load_tri(a.tverts, c0.x, A0, A1, A2);
+    load_tri(a.tverts, c0.y, B0, B1, B2);
+    const double da = tri_d2_screen(x, A0, A1, A2), db = tri_d2_screen(x, B0, B1, B2);
+    const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
+      fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
+    const double rb = sqrt(fmin(da, db)) + 1e-9 * (double)smax;
+    if (fmax(da, db) > rb * rb)
     {
-      d3 A0, A1, A2, B0, B1, B2;
-      load_tri(a.tverts, c0.x, A0, A1, A2);
-      load_tri(a.tverts, c0.y, B0, B1, B2);
-      const double da = tri_d2_screen(x, A0, A1, A2), db = tri_d2_screen(x, B0, B1, B2);
-      const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
-        fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
-      const double tau = 1e-9 * (double)smax;
-      const double rb = sqrt(fmin(da, db)) + tau;
-      if (fmax(da, db) > rb * rb)
-      {
-        bs = da < db ? c0.x : c0.y;
-        decided = true;
-      }
+      bs = da < db ? c0.x : c0.y;
+      decided = true;
     }
-    if (!decided)
-    {
-      // (members read one by one: an array of them indexed by the loop's counter would live
-      // in scratch memory)
-#pragma unroll 1
-      for (int i = 0; i < RING3; i++)
-      {
-        const int32_t mi = a.cand[p * RING3 + i];
-        if (mi < 0)
-          break;
-        d3 P0, P1, P2, cp;
-        double dd, w[3];
-        load_tri(a.tverts, mi, P0, P1, P2);
-        const int32_t id = a.tid[mi];
-        if (tri_eval(x, P0, P1, P2, cp, dd, w) && better(dd, id, bd2, bid))
-        {
-          bd2 = dd;
-          bid = id;
-          bs = mi;
-        }
-      }
-    }
-    a.hint_rw[p] = bs;
-    return bs;
   }
+  if (!decided)
+  {
+    // (members read one by one: an array of them indexed by the loop's counter would live in
+    // scratch memory)
+#pragma unroll 1
+    for (int i = 0; i < RING3; i++)
+    {
+      const int32_t mi = a.cand[p * RING3 + i];
+      if (mi < 0)
+        break;
+      d3 P0, P1, P2, cp;
+      double dd, w[3];
+      load_tri(a.tverts, mi, P0, P1, P2);
+      const int32_t id = a.tid[mi];
+      if (tri_eval(x, P0, P1, P2, cp, dd, w) && better(dd, id, bd2, bid))
+      {
+        bd2 = dd;
+        bid = id;
+        bs = mi;
+      }
+    }
+  }
+  a.hint_rw[p] = bs;
+  return bs;
 }
 
 // Certificates for the queries the search kernels left without one (k_certify_rest, run at

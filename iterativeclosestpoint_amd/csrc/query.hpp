@@ -300,7 +300,7 @@ struct FinalArgs
   int32_t* o_cell;
   double* o_dist;
   uint32_t* o_flag;
-  // partial sums, [gridDim.x][ICPX_NSUMS] (sums only)
+  // partial sums, [ICPX_NSUMS][gridDim.x] (sums only)
   double* partials;
   // a lean pass (k_finalize_mx<.., LEAN>): the certificates and what they refer to, the
   // contender sets (RING3 per query), the winners (rewritten for queries that stand on a
@@ -641,7 +641,8 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))
     if (threadIdx.x < NS)
       for (int w = 0; w < FIN_THREADS / 64; w++)
         v += red[w][threadIdx.x];
-    a.partials[(int64_t)blockIdx.x * ICPX_NSUMS + threadIdx.x] = v;
+    // (sum-major: the reduction's wavefront then reads 64 consecutive doubles, not one per line)
+    a.partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
   }
 }
 
@@ -834,7 +835,8 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(4))
       for (int w = 0; w < FIN_THREADS / 64; w++)
         v += (&feat[w][0][0])[slot];
     }
-    a.partials[(int64_t)blockIdx.x * ICPX_NSUMS + threadIdx.x] = v;
+    // (sum-major: the reduction's wavefront then reads 64 consecutive doubles, not one per line)
+    a.partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
   }
 }
 
@@ -898,7 +900,7 @@ __device__ __forceinline__ bool reduce_partials_body(
   }
   double v = 0.0;
   for (int b = l; b < nblocks; b += 64)
-    v += partials[(int64_t)b * ICPX_NSUMS + i];
+    v += partials[(int64_t)i * nblocks + b];
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1)
     v += __shfl_xor(v, m, 64);
