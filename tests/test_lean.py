@@ -97,3 +97,26 @@ def test_lean_passes_with_distance_threshold(icpx, synth):
         assert np.array_equal(res[mode][0], res[0][0]) and res[mode][1:4] == res[0][1:4], (mode, res[mode][4:])
     assert res[2][4] >= 5, res[2][4:]
     assert res[3][5] >= 1, res[3][4:]
+
+
+def test_lean_failures_at_the_end_of_a_run(icpx, synth):
+    """A lean pass that fails among the last passes of a run is found when the run's last records
+    are awaited, and repeated: runs of every length end as they do without lean passes."""
+    c = synth.config_c3(nu=300, nv=150, npts=120_000)
+    ctx = icpx.Context(0)
+    ctx.set_target(c["target_xyz"], c["target_tri"])
+    ctx.set_source(c["source_xyz"], c["source_normals"])
+    p = icpx.default_params()
+    p.metric, p.max_landmarks = 2, len(c["source_xyz"])
+    p.max_distance = c["max_dist"]
+    failures = 0
+    for iters in range(6, 16):
+        p.max_iterations = iters
+        ctx.set_lean(0)
+        T0, it0, m0, st0 = ctx.run(p)
+        ctx.set_lean(3)
+        before = ctx.debug_stats()["lean_failures"]
+        T3, it3, m3, st3 = ctx.run(p)
+        failures += ctx.debug_stats()["lean_failures"] - before
+        assert np.array_equal(T3, T0) and (it3, st3, m3) == (it0, st0, m0) and it0 == iters, iters
+    assert failures >= 5
