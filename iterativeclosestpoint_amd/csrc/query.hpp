@@ -840,6 +840,13 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(4))
   }
 }
 
+// k_search3w's pool counters among the pass counters: one per run of batches, in the word
+// after a segment count of k_certify's list (256 bytes apart; zero between passes)
+constexpr int XPOOLS = 8;
+constexpr int XPOOL_FIRST = 17;
+constexpr int XPOOL_STRIDE = 64;
+constexpr uint32_t XCHUNK = 128; // consecutive batches (of 64 queries) that belong to one run
+
 // Block partials -> the ICPX_NSUMS totals.  One 64-lane block per sum: lane l adds
 // partials l, l+64, ... in that order, then a fixed xor-shuffle tree; the shape
 // depends only on the number of blocks, so results repeat run to run.
@@ -883,6 +890,8 @@ __device__ __forceinline__ bool reduce_partials_body(
     uint32_t len = l < 32 ? counters[16 + l * 64] : 0u;
     if (l < 32)
       counters[16 + l * 64] = 0u;
+    if (l < XPOOLS)
+      counters[XPOOL_FIRST + l * XPOOL_STRIDE] = 0u; // (k_search3w's pool counters)
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1)
       len += __shfl_xor(len, m, 64);

@@ -82,6 +82,29 @@ def test_closest_point_matches_bruteforce(icpx, synth, small, width, exhaustive)
     assert {0, 1, 2} <= set(np.unique(ref["kind"]))  # face, edge and vertex normals all hit
 
 
+def test_wavefront_walk_deals_out_every_batch(icpx, synth, small):
+    """One walk per wavefront: batches of 64 queries are dealt out in chunks of 128 batches to
+    eight runs with a pool each.  Cloud sizes on both sides of a batch, of a chunk and of a
+    whole cycle of chunks: every query is served once (rows equal to the oracle's), cold and
+    from the last winners."""
+    c, mesh = small
+    nmax = 8 * 128 * 64 + 130
+    q_all = queries_around(synth, c["target_xyz"], c["target_tri"], nmax, seed=23)
+    ref_all = mesh.correspond(q_all, step=1, max_dist=1e30, grid=True)
+    assert np.array_equal(ref_all["src_index"], np.arange(nmax))
+    ctx = icpx.Context(0)
+    ctx.set_group_width(1)
+    ctx.set_persistent(3)
+    ctx.set_target(c["target_xyz"], c["target_tri"])
+    for n in (1, 63, 64, 65, 128 * 64 - 1, 128 * 64, 128 * 64 + 1, 3 * 128 * 64 + 64 * 5 + 7,
+              8 * 128 * 64 - 1, 8 * 128 * 64, nmax):
+        ctx.set_source(q_all[:n])
+        ref = {k: v[:n] for k, v in ref_all.items()}
+        check_rows(ctx.correspond(np.eye(4), step=1, max_dist=1e30), ref)
+        check_rows(ctx.correspond(np.eye(4), step=1, max_dist=1e30), ref)
+    ctx.close()
+
+
 def test_cube_known_answers(icpx):
     v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1],
                   [0, 1, 1]], np.float32)
