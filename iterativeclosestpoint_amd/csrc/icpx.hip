@@ -1975,9 +1975,11 @@ static int run_search3(icpx_ctx* c)
   // the wavefront walk, the pooled lanes and the shortcut keep certificates; the other
   // variants do not, and a pass of theirs leaves the certificates behind
   // (nor does the wavefront walk on a cold pass and the one after it: those moves outrun
-  // any certificate)
+  // any certificate; on a large cloud, where making certificates costs a pass milliseconds,
+  // nor on the third: measured on 16 M noisy points, the move after it still broke seven
+  // eighths of them)
   c->since_cold = c->hint_valid ? c->since_cold + 1 : 0;
-  c->pass_certs = c->use_cert && (mode == 1 || (mode == 3 && c->since_cold >= 2));
+  c->pass_certs = c->use_cert && (mode == 1 || (mode == 3 && c->since_cold >= (large_cloud(c) ? 3 : 2)));
   a.cert = c->pass_certs ? c->d_cert : nullptr;
   // a kernel that checks every query's certificate runs in this pass (the shortcut or
   // k_certify, or the wavefront walk over the whole cloud): it marks the queries that stand

@@ -663,7 +663,8 @@ def test_full_size_c4(icpx, synth, oracle):
     first two passes against golden vectors the CPU oracle produced on the same inputs
     (tools/make_c4_golden.py).  (2) The 50-iteration registration against the ground truth.
     (3) The light certificate kernel, and both tree kernels enqueued over a large cloud's
-    leftovers, did run.  (4) At the converged pose: a 5000-row sample against the oracle run
+    leftovers, did run (the wavefront walk over a list in a pass after a move that breaks most
+    certificates).  (4) At the converged pose: a 5000-row sample against the oracle run
     here, and properties of all 16M rows."""
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "c4_two_iterations.npz"))
     c = synth.config_c4()
@@ -697,14 +698,29 @@ def test_full_size_c4(icpx, synth, oracle):
     assert np.abs(T @ c["truth"] - np.eye(4)).max() < 3e-5   # the noise floor of the scan
     stats = ctx.debug_stats()
     assert stats["certify_passes"] >= 40, stats   # certificates checked by the light kernel
-    assert stats["split_wave"] >= 1 and stats["split_pool"] >= 30, stats
+    assert stats["split_pool"] >= 30, stats
     # (noisy points are beyond the neighbour lists' reach: after two listed passes that showed
     # it, the light kernel's list went straight to the tree kernels)
     assert stats["direct_passes"] >= 30, stats
+    # A move of a sixteenth of an edge length breaks most certificates: the light kernel's list
+    # is then most of the cloud and goes to the wavefront walk, not to the pooled lanes.
+    moved = synth.rigid(t=(1e-4, 0.0, 0.0)) @ T
+    rows = ctx.correspond(moved, step=1, max_dist=c["max_dist"])
+    after = ctx.debug_stats()
+    assert after["certify_passes"] == stats["certify_passes"] + 1, (stats, after)
+    assert after["split_passes"] == stats["split_passes"] + 1, (stats, after)
+    # (the list's length: on the wavefront walk's side of the split, so that kernel served it)
+    assert ctx.debug_counters()["fallback"] >= n // 2, ctx.debug_counters()
+    pick = (np.arange(2_000) * 7919 + 5).astype(np.int64)
+    mesh = oracle.Mesh(c["target_xyz"], c["target_tri"])
+    ref = mesh.correspond(c["source_xyz"][pick], T=moved, step=1, max_dist=c["max_dist"], grid=True)
+    assert np.array_equal(rows["src_index"], np.arange(n))
+    for key in ("cell", "dist", "closest"):
+        assert np.array_equal(rows[key][pick], ref[key]), key
+    del rows
     rows = ctx.correspond(T, step=1, max_dist=c["max_dist"])
     assert len(rows["cell"]) == n and np.array_equal(rows["src_index"], np.arange(n))
     pick = (np.arange(5_000) * 3137 + 11).astype(np.int64)
-    mesh = oracle.Mesh(c["target_xyz"], c["target_tri"])
     ref = mesh.correspond(c["source_xyz"][pick], T=T, step=1, max_dist=c["max_dist"], grid=True)
     for key in ("cell", "dist", "closest"):
         assert np.array_equal(rows[key][pick], ref[key]), key
