@@ -278,7 +278,7 @@ struct Search3Args
   // contested queries
   int32_t* cand;        // [nq][RING3]
   uint2* tie_list;      // {query, contenders}
-  uint32_t* counters;   // [0] ties, [1] overflows, [2] next query of the pool
+  uint32_t* counters;   // [0] ties, [1] overflows, [XPOOL_FIRST + r * XPOOL_STRIDE] next position of run r's pool
   uint32_t* ovf_list;   // queries with more contenders than the ring holds
   double* ovf_best;     // their screened minimum, indexed by query
   const uint32_t* qlist; // persistent kernel: serve only these queries (count in counters[3]), or null
@@ -619,7 +619,7 @@ __device__ __forceinline__ void search3_body(const Search3Args& a, unsigned bloc
 // widths off the surface meets a hundred boxes, a point on it a dozen), and with
 // one query per lane for the lifetime of a wavefront most lanes sit idle waiting
 // for the slowest; refilling keeps them busy.  Results are per query and do not
-// depend on which lane ran them.  counters[2] is the pool's next query.
+// depend on which lane ran them.  (The pool is dealt out in runs, one per L2 cache: see the draw.)
 #ifdef ICPX_STATS
 // development build only: totals over all queries of {node visits, leaves screened, visits that rejected both children,
 // triangle screens, loop iterations (per wavefront), refills}
@@ -658,7 +658,8 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
   int32_t sec_id = -1;
   float widen = 0.f;                        // margin by which the walk looks farther (widen_of)
   bool have = false, fin = false, need_bt = false, atleaf = false;
-  bool dry = false; // the pool has run out (same for every lane of the wavefront)
+  bool dry = false; // the pools have run out (same for every lane of the wavefront)
+  uint32_t tried = 0; // runs this wavefront has found used up
   const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
   if ((int64_t)blockIdx.x * 256 >= total)
     return; // a short list is served by the first blocks; the rest must not queue at the pool
@@ -750,11 +751,17 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
         const bool want = !have;
         const unsigned long long mw = __ballot(want);
         const int leader = __ffsll((long long)mw) - 1;
+        // (the queries are dealt out as k_search3w's batches are, by the L2 cache the block's
+        // number goes with: chunks of XCHUNK * 64 consecutive queries to XPOOLS runs in turn,
+        // a pool counter per run, a wavefront whose run is used up goes on to the next one's)
+        constexpr uint32_t CHQ = XCHUNK * 64u;
+        const uint32_t seg = (blockIdx.x + tried) % (uint32_t)XPOOLS;
         uint32_t base = 0;
         if (lane == leader)
-          base = atomicAdd(&a.counters[2], (uint32_t)__popcll(mw));
+          base = atomicAdd(&a.counters[XPOOL_FIRST + seg * XPOOL_STRIDE], (uint32_t)__popcll(mw));
         base = __shfl(base, leader, 64);
-        const int64_t nq_ = (int64_t)base + __popcll(mw & lt);
+        const uint32_t t = base + (uint32_t)__popcll(mw & lt);
+        const int64_t nq_ = ((int64_t)(t / CHQ) * XPOOLS + seg) * CHQ + t % CHQ;
         if (want && nq_ < total)
         {
           q = a.qlist ? (int64_t)a.qlist[nq_] : nq_;
@@ -813,11 +820,17 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
             }
           }
         }
-        dry = __ballot(want && nq_ >= total) != 0ull;
+        // (positions rise with the draws: a run that has handed out one past the end is used up)
+        if (__ballot(want && nq_ >= total) != 0ull)
+          dry = ++tried >= (uint32_t)XPOOLS;
       }
       STAT(5, lane == 0 ? 1 : 0);
       if (__ballot(have) == 0ull)
-        break;
+      {
+        if (dry)
+          break;
+        continue; // (the next run's pool)
+      }
     }
     STAT(4, lane == 0 ? 1 : 0);
 
@@ -1022,8 +1035,8 @@ __device__ __forceinline__ float tri_lb_rec(float nx, float ny, float nz, float 
 // When some lane's queue is full, and when the walk is over, the queues are weeded (entries
 // the bound has overtaken go unscreened) and every lane screens its most promising entry in
 // fp64: the bound that leaves behind turns most of the others away, and the screen runs with
-// most lanes busy.  Wavefronts draw blocks of 64 queries from
-// counters[2].  Results per query are those of k_search3p: bounds only ever remove
+// most lanes busy.  Wavefronts draw batches of 64 queries from the
+// pools.  Results per query are those of k_search3p: bounds only ever remove
 // triangles that cannot be contenders, and a triangle is a contender by the same per-lane
 // test whatever the order of the walk.
 typedef float vec4f __attribute__((ext_vector_type(4)));
