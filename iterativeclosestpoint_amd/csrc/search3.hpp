@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
   // b + 8 share one of the chip's eight L2 caches and the queries are in Morton order, so
   // each cache sees the nodes and leaves of a few stretches of the cloud instead of a share
   // of everything the resident grid is walking, whose footprint is several times a cache's
-  // size (memory-side reads of a cold pass over 16 M queries: 17 GB before, 4.6 GB so).
+  // size (memory-side reads of a cold pass over 16 M queries: 17 GB before, 5.5 GB so).
   // The runs advance through the cloud together, so they end together; a wavefront whose
   // run is used up goes on with the next one's.  (Placement is a matter of speed only: any
   // wavefront may take any batch.)
