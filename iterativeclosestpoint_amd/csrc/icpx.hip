@@ -260,6 +260,9 @@ constexpr int64_t CERTIFY_MIN = 4000000;
 // pass counters: {ties, overflows, pool position, shortcut fallbacks}, the last pass's copy
 // of the four, then (from word 16) the segment counts of k_certify's list
 constexpr int PASS_COUNTERS = 16 + CERTIFY_SEGS * CERTIFY_SEG_STRIDE;
+static_assert(XPOOL_FIRST + (XPOOLS - 1) * XPOOL_STRIDE < PASS_COUNTERS && XPOOL_FIRST > 16 &&
+    (XPOOL_FIRST - 16) % CERTIFY_SEG_STRIDE != 0 && XPOOL_STRIDE == CERTIFY_SEG_STRIDE,
+  "the tree kernels' pool counters lie among the pass counters, beside the list's segment counts");
 
 struct icpx_ctx
 {
