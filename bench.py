@@ -90,6 +90,19 @@ def main():
                     help="development: one rank, but through the multi-rank loop with its all-reduce")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="development: leave out the HIP events around the search kernels")
+    ap.add_argument("--emulate-shard", default="",
+                    help="R/N: this one process runs rank R's share of an N-rank strong-scaling job "
+                         "through the multi-rank loop, without a collective (what one rank of N does; "
+                         "0/1 = one rank's share of a weak-scaling job)")
+    ap.add_argument("--shard-order", type=int, default=-1,
+                    help="development: 1 shards by the curve order (default), 0 by blocks of indices")
+    ap.add_argument("--certify-min", type=int, default=-1,
+                    help="development: queries per rank from which the large-cloud policy applies")
+    ap.add_argument("--lean", type=int, default=-1, help="development: icpx_set_lean")
+    ap.add_argument("--noisy-policy", type=int, default=-1, help="development: icpx_set_noisy_policy")
+    ap.add_argument("--curve", type=int, default=-1, help="development: icpx_set_query_curve")
+    ap.add_argument("--dump-passes", action="store_true",
+                    help="development: the search kernels' median time of every pass into config")
     ap.add_argument("--timing-every", type=int, default=4,
                     help="the search kernels of every N-th timed registration carry HIP events")
     args = ap.parse_args()
@@ -126,11 +139,30 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     strong = args.scaling == "strong"
+    emu = None
+    if args.emulate_shard:
+        emu = tuple(int(v) for v in args.emulate_shard.split("/"))
+        if world != 1 or len(emu) != 2 or not 0 <= emu[0] < emu[1]:
+            raise SystemExit("--emulate-shard R/N needs one process and 0 <= R < N")
+        strong = True
     c = make_workload(args.workload, rank, synth, own_scan=not strong)
     npts, nt, nv = len(c["source_xyz"]), len(c["target_tri"]), len(c["target_xyz"])
     metric = c["metric"]
     # weak: the local scan is this rank's whole shard; strong: a share of the one cloud
-    sh = ShardedICP(device=local, rank=rank if strong else 0, world=world if strong else 1)
+    if emu:
+        sh = ShardedICP(device=local, rank=emu[0], world=emu[1])
+    else:
+        sh = ShardedICP(device=local, rank=rank if strong else 0, world=world if strong else 1)
+    if args.shard_order >= 0:
+        sh.ctx.set_shard_order(args.shard_order)
+    if args.certify_min >= 0:
+        sh.ctx.set_certify_min(args.certify_min)
+    if args.lean >= 0:
+        sh.ctx.set_lean(args.lean)
+    if args.noisy_policy >= 0:
+        sh.ctx.set_noisy_policy(args.noisy_policy)
+    if args.curve >= 0:
+        sh.ctx.set_query_curve(args.curve)
     if args.width:
         sh.ctx.set_group_width(args.width)
     if args.leaf:
@@ -140,8 +172,12 @@ def main():
     sh.set_target(c["target_xyz"], c["target_tri"])
     sh.set_source(c["source_xyz"], c["source_normals"])
     build_s = sh.ctx.build_seconds
-    nq_rank = npts if not strong else (npts * (rank + 1) // world - npts * rank // world)
+    from iterativeclosestpoint_amd.distributed import shard_size
+    nq_rank = npts if not strong else shard_size(npts, rank, world)
     nq_job = npts * world if not strong else npts
+    if emu:  # (with --shard-order 0 or 1 the shard is an equal share to within a point)
+        nq_rank = nq_job = shard_size(npts, emu[0], emu[1]) if args.shard_order < 0 or args.shard_order == 2 \
+            else npts * (emu[0] + 1) // emu[1] - npts * emu[0] // emu[1]
 
     params = icpx.default_params()
     params.metric = metric
@@ -152,7 +188,8 @@ def main():
 
     def registration():
         """One vtkICP::Update(): ITERATIONS iterations from a cold start."""
-        T, it, md, status = sh.run_device(params, force_collective=args.force_collective)
+        T, it, md, status = sh.run_device(params, force_collective=args.force_collective,
+                                          emulate=emu is not None)
         if it != ITERATIONS:
             raise SystemExit("registration stopped after %d of %d iterations" % (it, ITERATIONS))
         return T, md
@@ -250,6 +287,10 @@ def main():
                 "world_size": dist.get_world_size() if collective else 1,
                 "backend": dist.get_backend() if collective else "none",
                 "one_rank_check_rel": one_rank_check,
+                "emulated_shard": ("rank %d of %d: this process ran that rank's share of the job (%d points) "
+                                   "through the multi-rank loop without a collective; value is that "
+                                   "rank's rate" % (emu[0], emu[1], nq_rank)) if emu else None,
+                "passes": sh.ctx.debug_stats(),
             },
         }
         if pass_rows:
@@ -276,6 +317,9 @@ def main():
             ach_cold = b_cold / (cold * 1e-3) / 1e9
             ach_steady = b_steady / (steady * 1e-3) / 1e9
             search_total = float(pm.sum(1).mean())
+            if args.dump_passes:
+                out["config"]["pass_ms"] = [round(float(v), 4) for v in np.median(pm, 0)]
+                out["config"]["pass_kind"] = [int(v) for v in np.array(kind_rows)[0]]
             out["config"]["cold_pass_corr_per_s"] = nq_rank / (cold * 1e-3)
             out["config"]["steady_pass_corr_per_s"] = nq_rank / (steady * 1e-3)
             out["config"]["search_kernels_ms_per_registration"] = search_total

@@ -98,8 +98,19 @@ extern "C"
   int icpx_set_source(
     icpx_ctx* ctx, const float* xyz, int64_t np, const float* normals_or_null);
 
-  /* Restrict this context to shard `rank` of `world` equal contiguous blocks
-   * of the kept source indices {0, step, 2*step, ...}.  Default (0, 1). */
+  /* Restrict this context to shard `rank` of `world` of the kept source points
+   * {0, step, 2*step, ...}.  Default (0, 1).  The kept points are ordered along a
+   * space-filling curve through the target's bounds, and chunks of that order (8192
+   * points; fewer for a small cloud) are dealt out to the ranks in turn: a rank's
+   * points come in runs of neighbours on the surface, which its searches share work
+   * over, and every rank has its share of every part of the surface.  Every rank
+   * works the order out for itself from the same source and target, with the same
+   * result; shards differ in size by a chunk at most.  Sums of the shards add up to
+   * the sums of the whole (in another order of additions: to rounding); rows of a
+   * shard (icpx_correspond) come out by ascending source index and the shards' rows
+   * together are the rows of the whole.  The reference has one process; the points
+   * are independent of one another there too
+   * (ICP/vtkPolyDataCorrespondenceFilter.cxx:110-136). */
   int icpx_set_shard(icpx_ctx* ctx, int rank, int world);
 
   /* Point about which the raw moments are taken (centre of the target's
@@ -139,8 +150,9 @@ extern "C"
    * allocate, come first); the ICPX_NSUMS sums are left in the caller's device buffer
    * sums_device, stream-ordered; arguments otherwise as icpx_accumulate.  Same sums, bit
    * for bit, as icpx_accumulate gives for the same arguments.
-   * Limits: at most ICPX_STATIC_MAX_QUERIES kept points in this context's shard (more is
-   * ICPX_E_INVALID: use icpx_accumulate or a larger step), and the search tree of that size
+   * Limits: at most ICPX_STATIC_MAX_QUERIES kept points in this context's shard (in the whole
+   * job when the context is one of several shards: all of them are ordered to cut the shard
+   * out; more is ICPX_E_INVALID: use icpx_accumulate or a larger step), and the search tree of that size
    * class must exist: one earlier icpx_accumulate call on this target with a step of the
    * same size class (up to 4096 kept points, or more) builds it, otherwise ICPX_E_INVALID.
    * Every call on one GPU, from any context, uses that GPU's one array: calls that overlap
@@ -262,9 +274,35 @@ extern "C"
    *   icpx_run_end(ctx, T, &iters, &mean, &status);   // waits for the stream
    *
    * sums_device = NULL uses an internal buffer (single GPU; icpx_run does exactly that).
-   * Replaces ICP/vtkICP.cxx:189-246 like icpx_run; the reference has no multi-GPU loop. */
+   * Replaces ICP/vtkICP.cxx:189-246 like icpx_run; the reference has no multi-GPU loop.
+   *
+   * icpx_run_advance is icpx_run_enqueue for a loop that lets the library keep the
+   * position, which is what the ranks of a multi-GPU job should run:
+   *
+   *   icpx_run_begin(ctx, p);
+   *   for (;;) {
+   *     icpx_run_advance(ctx, sums_dev, &more);   // the next pass, if there is one
+   *     if (!more) break;
+   *     all-reduce (sum) all ICPX_NSUMS doubles of sums_dev in place on the same stream;
+   *     icpx_run_update(ctx, sums_dev);
+   *   }
+   *   icpx_run_end(ctx, T, &iters, &mean, &status);
+   *
+   * The spare slots of the sum vector then carry every rank's pass figures (queries
+   * searched, queries the shortcut left to the tree walk, a flag) through the all-reduce,
+   * so that all ranks read the same iteration records, decide alike and enqueue the same
+   * sequence of passes and collectives.  That allows what icpx_run does on one rank: once
+   * the registration has settled, a pass is tried as two launches (the check that no
+   * query's winner can have changed inside the kernel that makes the sums, then the
+   * reduction); if any rank meets a query it cannot answer that way, the flag makes every
+   * rank drop that pass, the position goes back to it and it is repeated with the search
+   * kernels.  Same transform, iteration count and status as the counted loop above.  A
+   * run is driven by one of icpx_run_enqueue and icpx_run_advance, not both; every rank
+   * of a job must use the same one, the same parameters and the same development
+   * switches (icpx_dev.h). */
   int icpx_run_begin(icpx_ctx* ctx, const icpx_params* p);
   int icpx_run_enqueue(icpx_ctx* ctx, double* sums_device, int* done_out);
+  int icpx_run_advance(icpx_ctx* ctx, double* sums_device, int* more_out);
   int icpx_run_update(icpx_ctx* ctx, const double* sums_device);
   int icpx_run_end(icpx_ctx* ctx, double T_out[16], int* iterations_out,
     double* mean_distance_out, int* status_out);

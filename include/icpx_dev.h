@@ -87,6 +87,35 @@ extern "C"
    * Same results to the last bit. */
   int icpx_set_lean(icpx_ctx* ctx, int enable);
 
+  /* How icpx_set_shard cuts the kept points into shards: 2 (default) = the kept points are
+   * ordered along the space-filling curve through the target's bounds and chunks of that order
+   * (8192 points; fewer for a small cloud, so that every rank has at least eight) are dealt
+   * out to the ranks in turn; 1 = `world` equal ranges of that order, one stretch of the
+   * surface per rank (the ranks' first passes then differ by a factor of two: some stretches
+   * are farther from their place than others); 0 = blocks of consecutive kept indices (each
+   * rank's points lie all over the surface, `world` times sparser).  1 and 0 are kept for
+   * measurements.  Sums over all shards are the same to rounding. */
+  int icpx_set_shard_order(icpx_ctx* ctx, int order);
+
+  /* 1 (default): a cloud of a quarter of a million points or more per rank whose mean residual
+   * stays beyond the reach of the shortcut's neighbour lists (a noisy scan) goes by the large
+   * cloud's policy whatever its size; 0: the policy goes by size alone.  For measurements. */
+  int icpx_set_noisy_policy(icpx_ctx* ctx, int enable);
+
+  /* Number of queries per rank from which a pass's certificates are checked by the light
+   * kernel of their own and the host's policy treats the cloud as a large one (default four
+   * million; negative restores it).  For measurements of where that boundary belongs. */
+  int icpx_set_certify_min(icpx_ctx* ctx, int64_t queries);
+
+  /* Resident single-wavefront blocks per CU of the one-walk-per-wavefront kernel (default 19:
+   * what its registers and LDS allow).  For measurements. */
+  int icpx_set_wave_blocks(icpx_ctx* ctx, int blocks_per_cu);
+
+  /* The curve the kept source points are ordered along (for the wavefronts' batches of 64
+   * consecutive queries, and for the shards): 1 (default) = Hilbert, 0 = Morton.  Same
+   * results; the sums' additions come in another order. */
+  int icpx_set_query_curve(icpx_ctx* ctx, int hilbert);
+
   /* Search kernel selection.  0 (default): the production kernel, which screens
    * triangles with a short fp64 routine and evaluates only near-ties (within
    * 1e-9 x the largest coordinate of the minimum) with the reference's exact

@@ -83,6 +83,54 @@ __device__ __forceinline__ uint64_t morton63(float x, float y, float z, const fl
   return (spread21(qx) << 2) | (spread21(qy) << 1) | spread21(qz);
 }
 
+// Position along the Hilbert curve through the same 2^21 grid (Skilling's transform of the
+// three coordinates, then the same interleave).  Consecutive positions are neighbouring grid
+// cells without exception, where the Morton curve jumps across the box whenever a high bit
+// flips: a run of consecutive points is one compact patch, never two far apart.
+__device__ __forceinline__ uint64_t hilbert63(float x, float y, float z, const float* lo,
+  const float* inv)
+{
+  float fx = (x - lo[0]) * inv[0], fy = (y - lo[1]) * inv[1], fz = (z - lo[2]) * inv[2];
+  fx = fminf(fmaxf(fx, 0.f), 1.f);
+  fy = fminf(fmaxf(fy, 0.f), 1.f);
+  fz = fminf(fmaxf(fz, 0.f), 1.f);
+  uint32_t X0 = min((uint32_t)(fx * 2097152.f), 2097151u);
+  uint32_t X1 = min((uint32_t)(fy * 2097152.f), 2097151u);
+  uint32_t X2 = min((uint32_t)(fz * 2097152.f), 2097151u);
+  for (uint32_t Q = 1u << 20; Q > 1u; Q >>= 1)
+  {
+    const uint32_t P = Q - 1u;
+    if (X0 & Q)
+      X0 ^= P;
+    if (X1 & Q)
+      X0 ^= P;
+    else
+    {
+      const uint32_t t = (X0 ^ X1) & P;
+      X0 ^= t;
+      X1 ^= t;
+    }
+    if (X2 & Q)
+      X0 ^= P;
+    else
+    {
+      const uint32_t t = (X0 ^ X2) & P;
+      X0 ^= t;
+      X2 ^= t;
+    }
+  }
+  X1 ^= X0;
+  X2 ^= X1;
+  uint32_t t = 0u;
+  for (uint32_t Q = 1u << 20; Q > 1u; Q >>= 1)
+    if (X2 & Q)
+      t ^= Q - 1u;
+  X0 ^= t;
+  X1 ^= t;
+  X2 ^= t;
+  return (spread21(X0) << 2) | (spread21(X1) << 1) | spread21(X2);
+}
+
 struct Box3
 {
   float lo[3], inv[3];
@@ -104,15 +152,17 @@ __global__ void k_morton_tris(const float* __restrict__ xyz, const int32_t* __re
   vals[c] = (uint32_t)c;
 }
 
-// Morton code of the kept source points of a shard (point (k0+q)*step), value = q.
+// Place on the space-filling curve of the kept source points of a shard (point (k0+q)*step),
+// value = q.  hilbert: the Hilbert curve (the queries' order: a wavefront's 64 consecutive
+// queries are then always one patch); else the Morton curve.
 __global__ void k_morton_points(const float* __restrict__ xyz, int64_t k0, int64_t step,
-  int64_t nq, Box3 b, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+  int64_t nq, Box3 b, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int hilbert = 1)
 {
   int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq)
     return;
   const float* p = xyz + 3 * ((k0 + q) * step);
-  keys[q] = morton63(p[0], p[1], p[2], b.lo, b.inv);
+  keys[q] = hilbert ? hilbert63(p[0], p[1], p[2], b.lo, b.inv) : morton63(p[0], p[1], p[2], b.lo, b.inv);
   vals[q] = (uint32_t)q;
 }
 

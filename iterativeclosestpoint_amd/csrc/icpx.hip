@@ -121,17 +121,38 @@ __global__ void k_cert_mark(RunState* s, int mode, double cap2)
 
 // (one build per metric: with the metric a run-time value all three solvers are part of the
 // kernel, 41 KB of code of which a launch runs a quarter, straight through, once)
+// share: the sums were all-reduced over the ranks of a job with every rank's policy figures
+// in their spare slots (state.hpp: SLOT_*): the record carries the job's totals, and a lean
+// pass that failed on ANY rank is dropped here on EVERY rank (nothing is solved, the
+// registration is suspended, done = 2, until the hosts, which all read the same in their
+// records, repeat the pass in full).
 template <int METRIC>
 __global__ void k_solve(RunState* s, const double* __restrict__ sums, double ox,
   double oy, double oz, int check_mean, double max_mean, const uint32_t* __restrict__ counters,
-  RunRecord* rec, uint32_t seq, float src_rmax, float anchor_reach)
+  RunRecord* rec, uint32_t seq, float src_rmax, float anchor_reach, int share)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0)
     return;
   const double origin[3] = { ox, oy, oz };
-  solve_and_publish(s, sums, METRIC, origin, check_mean, max_mean, true, counters ? counters[7] : 0u,
-    counters ? counters[8] : 0u, counters ? counters[4] + counters[5] : 0u, rec, seq, src_rmax,
-    anchor_reach);
+  uint32_t fallback = counters ? counters[7] : 0u, listed = counters ? counters[8] : 0u,
+           contested = counters ? counters[4] + counters[5] : 0u, nq_total = 0u;
+  bool ran = true;
+  if (share)
+  {
+    fallback = slot_count(sums[SLOT_FALLBACK]);
+    listed = slot_count(sums[SLOT_LISTED]);
+    contested = slot_count(sums[SLOT_CONTESTED]);
+    nq_total = slot_count(sums[SLOT_NQ]);
+    if (!(sums[SLOT_LEANFAIL] == 0.0)) // (some rank's flag, or not a number: the pass counts for nothing)
+    {
+      ran = false;
+      if (s->done == 0)
+        s->done = 2;
+    }
+    s->lean_fail = 0;
+  }
+  solve_and_publish(s, sums, METRIC, origin, check_mean, max_mean, ran, fallback, listed, contested,
+    rec, seq, src_rmax, anchor_reach, nq_total);
 }
 
 // Largest |v[i]| as a float's bits (*out starts at zero; a NaN or infinity ends up on top).
@@ -296,6 +317,8 @@ struct icpx_ctx
   int leaf_size = 4;
   int persistent = 4; // tree kernel: 1 pooled lanes, 3 one walk per wavefront, 4 by regime
   int wave_blocks = 19; // blocks per CU of the one-walk-per-wavefront kernel
+  int noisy_policy = 1; // a cloud that stays beyond the lists' reach goes by the large cloud's policy (heavy_cloud)
+  int query_curve = 1;  // the queries' order: 1 along the Hilbert curve, 0 along the Morton curve
   int num_cus = 256;
   // hinted shortcut: per-leaf neighbour lists for one radius, and the residual statistics
   // of the previous pass that choose the radius
@@ -367,6 +390,8 @@ struct icpx_ctx
   // the pass's record, takes the loop back to that pass and repeats it in full.
   int use_lean = 1;
   bool run_fused = false;     // this run is one rank's fused loop
+  bool run_shared = false;    // this run is a rank's share of a multi-rank loop (icpx_run_advance)
+  bool last_lean = false;     // the pass enqueued last was a lean one (its solve is still to come)
   bool lean_pairs_pass = false; // the pass being enqueued prepares certificates for lean passes
   bool lean_base = false;     // the pass enqueued last left every certificate up to date the shortcut's way
   bool clean_noted = false;   // the last record looked at was of a pass that left nothing over
@@ -395,12 +420,23 @@ struct icpx_ctx
   float* d_srcn = nullptr;
   uint64_t src_version = 0;
   int rank = 0, world = 1;
+  // How the kept points are cut into shards.  They are ordered along the space-filling curve
+  // through the target's bounds; 2 (default): chunks of that order (8192 points, fewer for a
+  // small cloud) are dealt out to the ranks in turn, so that a rank's wavefronts hold
+  // neighbours on the surface, as one rank's do, and every rank has its share of every part
+  // of the surface, the parts that are far from their place at the start included; 1: `world`
+  // equal ranges of the order (one stretch of the surface per rank); 0: blocks of consecutive
+  // kept indices, whatever the points' places.
+  int shard_order = 2;
 
   // queries prepared for (step, shard, source version)
   int64_t prep_step = -1;
-  int prep_rank = -1, prep_world = -1;
+  int prep_rank = -1, prep_world = -1, prep_order = -1;
   uint64_t prep_version = 0;
   int64_t nq = 0, k0 = 0, q_cap = 0;
+  int64_t nk = 0;               // kept points of the whole job (all shards)
+  bool curve_shard = false;     // the prepared shard is a range of the curve order
+  int32_t* d_kglobal = nullptr; // ... then: slot (rank among the shard's kept indices) -> kept index
   float* d_qpos = nullptr;
   float* d_qsn = nullptr;
   int32_t* d_qk = nullptr;
@@ -639,6 +675,7 @@ static void free_queries(icpx_ctx* c)
   dev_free(&c->d_qsn);
   dev_free(&c->d_qk);
   dev_free(&c->d_hint);
+  dev_free(&c->d_kglobal);
   dev_free(&c->d_cand);
   dev_free(&c->d_tie_list);
   dev_free(&c->d_counters);
@@ -952,6 +989,15 @@ extern "C" int icpx_stats_read(icpx_ctx* c, unsigned long long out[8])
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(icpx::g_stats), z, sizeof(z)));
   return ICPX_OK;
 }
+extern "C" int icpx_stats_read_batches(icpx_ctx* c, unsigned long long out[37])
+{
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(icpx::g_stats_batch), sizeof(unsigned long long) * 37));
+  unsigned long long z[37] = { 0 };
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(icpx::g_stats_batch), z, sizeof(z)));
+  return ICPX_OK;
+}
 #endif
 
 extern "C" int icpx_set_leaf_size(icpx_ctx* c, int triangles)
@@ -1017,6 +1063,52 @@ extern "C" int icpx_set_lean(icpx_ctx* c, int enable)
     return fail(ICPX_E_INVALID, "lean passes: 0 (off), 1 (on), 2 (tried at every chance) or 3 (as 2, "
                                 "every third one made to fail), got %d", enable);
   c->use_lean = enable;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_shard_order(icpx_ctx* c, int order)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  if (order < 0 || order > 2)
+    return fail(ICPX_E_INVALID, "shard order must be 0 (blocks of kept indices), 1 (ranges of "
+                                "the curve order) or 2 (chunks of it dealt out in turn), got %d", order);
+  c->shard_order = order;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_wave_blocks(icpx_ctx* c, int blocks_per_cu)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  if (blocks_per_cu < 1 || blocks_per_cu > 32)
+    return fail(ICPX_E_INVALID, "blocks per CU must be 1..32, got %d", blocks_per_cu);
+  c->wave_blocks = blocks_per_cu;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_query_curve(icpx_ctx* c, int hilbert)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  c->query_curve = hilbert ? 1 : 0;
+  c->prep_step = -1; // (the queries are ordered anew)
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_noisy_policy(icpx_ctx* c, int enable)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  c->noisy_policy = enable ? 1 : 0;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_certify_min(icpx_ctx* c, int64_t queries)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  c->certify_min = queries < 0 ? CERTIFY_MIN : queries;
   return ICPX_OK;
 }
 
@@ -1541,7 +1633,46 @@ extern "C" int icpx_set_shard(icpx_ctx* c, int rank, int world)
   return ICPX_OK;
 }
 
+// Which kept points are this context's shard (icpx_ctx::shard_order).  Returns whether the
+// shard is cut from the curve order of all nk kept points (then *map says which positions of
+// that order are its queries, *nq how many); otherwise it is kept indices [*k0, *k0 + *nq).
+static bool shard_extent(const icpx_ctx* c, int64_t nk, int64_t* k0, int64_t* nq, ShardMap* map)
+{
+  const int r = c->rank, w = c->world;
+  *k0 = nk * r / w;
+  *nq = nk * (r + 1) / w - *k0;
+  map->rank = 0;
+  map->world = 1;
+  map->chunk = std::max<int64_t>(nk, 1);
+  if (w == 1 || c->shard_order == 0)
+    return false;
+  if (c->shard_order == 1)
+  {
+    // one range per rank: positions [k0, k0 + nq), i.e. one chunk that starts at k0
+    // (pos(j) = j with the order's pointer moved up by k0: prepare_queries does that)
+    return true;
+  }
+  int64_t chunk = 8192;
+  while (chunk > 1 && nk < 8 * w * chunk)
+    chunk /= 2; // (a small cloud: at least eight chunks per rank)
+  const int64_t nchunks = (nk + chunk - 1) / chunk;
+  const int64_t mine = r < nchunks ? (nchunks - r + w - 1) / w : 0;
+  int64_t n = mine * chunk;
+  if (mine > 0 && (nchunks - 1) % w == r && nk % chunk != 0)
+    n -= chunk - nk % chunk; // (the order's last chunk is a short one)
+  *k0 = 0;
+  *nq = n;
+  map->rank = r;
+  map->world = w;
+  map->chunk = chunk;
+  return true;
+}
+
 // Kept points of this shard, gathered in Morton order (relative to the target's bounds).
+// One rank, or shards by blocks of kept indices: the shard's own points are ordered.  Shards
+// by the curve (the default for several ranks): ALL kept points are ordered (every rank does
+// that for itself, from the same source and the same bounds, with a stable sort: the same
+// order everywhere) and the shard is the positions of that order that shard_extent names.
 static int prepare_queries(icpx_ctx* c, int64_t step)
 {
   if (c->nt == 0)
@@ -1551,11 +1682,13 @@ static int prepare_queries(icpx_ctx* c, int64_t step)
   if (step < 1)
     return fail(ICPX_E_INVALID, "step must be >= 1");
   if (c->prep_step == step && c->prep_rank == c->rank && c->prep_world == c->world &&
-    c->prep_version == c->src_version)
+    c->prep_order == c->shard_order && c->prep_version == c->src_version)
     return ICPX_OK;
   const int64_t nk = (c->np + step - 1) / step;
-  const int64_t k0 = nk * c->rank / c->world, k1 = nk * (c->rank + 1) / c->world;
-  const int64_t nq = k1 - k0;
+  int64_t k0 = 0, nq = 0;
+  ShardMap map;
+  const bool curve = shard_extent(c, nk, &k0, &nq, &map);
+  const int64_t nsort = curve ? nk : nq; // points that are ordered here
   hipStream_t st = c->stream;
   if (nq > c->q_cap)
   {
@@ -1563,31 +1696,64 @@ static int prepare_queries(icpx_ctx* c, int64_t step)
     ALLOC(c->d_qsn, 3 * nq);
     ALLOC(c->d_qk, nq);
     ALLOC(c->d_hint, nq);
+    ALLOC(c->d_kglobal, nq);
     c->q_cap = nq;
   }
   if (nq > 0)
   {
     uint64_t *ka = nullptr, *kb = nullptr;
     uint32_t *va = nullptr, *vb = nullptr, *scr = nullptr;
-    int rc = dev_alloc(&ka, nq);
+    int rc = dev_alloc(&ka, nsort);
     if (!rc)
-      rc = dev_alloc(&kb, nq);
+      rc = dev_alloc(&kb, nsort);
     if (!rc)
-      rc = dev_alloc(&va, nq);
+      rc = dev_alloc(&va, nsort);
     if (!rc)
-      rc = dev_alloc(&vb, nq);
+      rc = dev_alloc(&vb, nsort);
     if (!rc)
-      rc = dev_alloc(&scr, rs_scratch_words(nq));
+      rc = dev_alloc(&scr, rs_scratch_words(nsort));
     hipError_t e = hipSuccess;
-    if (!rc)
+    if (!rc && !curve)
     {
-      k_morton_points<<<nblk(nq, 256), 256, 0, st>>>(c->d_src, k0, step, nq, c->box, ka, va);
+      k_morton_points<<<nblk(nq, 256), 256, 0, st>>>(c->d_src, k0, step, nq, c->box, ka, va, c->query_curve);
       int which = radix_sort_pairs(ka, va, kb, vb, nq, 63, scr, st);
       k_gather_queries<<<nblk(nq, 256), 256, 0, st>>>(c->d_src, c->d_srcn, which ? vb : va, k0,
         step, nq, c->d_qpos, c->d_qsn, c->d_qk, c->d_hint);
       e = hipGetLastError();
       if (e == hipSuccess)
         e = hipStreamSynchronize(st);
+    }
+    else if (!rc)
+    {
+      k_morton_points<<<nblk(nk, 256), 256, 0, st>>>(c->d_src, 0, step, nk, c->box, ka, va, c->query_curve);
+      const int which = radix_sort_pairs(ka, va, kb, vb, nk, 63, scr, st);
+      // (the order stays in one pair of buffers; the other pair and the scratch, which are
+      // sized for nk >= nq, serve the second sort: the shard's kept indices, ascending)
+      const uint32_t* order = (which ? vb : va) + k0; // (k0: a range's start; 0 for chunks)
+      uint64_t* k2a = which ? ka : kb;
+      uint32_t* v2a = which ? va : vb;
+      // (two more buffers of nq: the sort ping-pongs)
+      uint64_t* k2b = nullptr;
+      uint32_t* v2b = nullptr;
+      rc = dev_alloc(&k2b, nq);
+      if (!rc)
+        rc = dev_alloc(&v2b, nq);
+      if (!rc)
+      {
+        k_shard_keys<<<nblk(nq, 256), 256, 0, st>>>(order, map, nq, k2a, v2a);
+        const int w2 = radix_sort_pairs(k2a, v2a, k2b, v2b, nq, 32, scr, st);
+        k_shard_slots<<<nblk(nq, 256), 256, 0, st>>>(w2 ? k2b : k2a, w2 ? v2b : v2a, nq,
+          c->d_kglobal, c->d_qk);
+        k_gather_queries_curve<<<nblk(nq, 256), 256, 0, st>>>(c->d_src, c->d_srcn, order, map,
+          step, nq, c->d_qpos, c->d_qsn, c->d_hint);
+        e = hipGetLastError();
+        if (e == hipSuccess)
+          e = hipStreamSynchronize(st);
+      }
+      else
+        (void)hipStreamSynchronize(st);
+      dev_free(&k2b);
+      dev_free(&v2b);
     }
     dev_free(&ka);
     dev_free(&kb);
@@ -1600,10 +1766,13 @@ static int prepare_queries(icpx_ctx* c, int64_t step)
       return fail(ICPX_E_HIP, "query ordering failed: %s", hipGetErrorString(e));
   }
   c->nq = nq;
+  c->nk = nk;
   c->k0 = k0;
+  c->curve_shard = curve;
   c->prep_step = step;
   c->prep_rank = c->rank;
   c->prep_world = c->world;
+  c->prep_order = c->shard_order;
   c->prep_version = c->src_version;
   c->hint_valid = false;
   return ICPX_OK;
@@ -1661,11 +1830,13 @@ static int ensure_bin(icpx_ctx* c, int L)
   return ICPX_OK;
 }
 
+static bool heavy_cloud(const icpx_ctx* c);
+
 template <int L>
 static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, unsigned pgrid,
   unsigned wgrid, int mode, const Search2Args* wide, hipStream_t st)
 {
-  if (pgrid && mode == 1 && a.qlist && a.cert && a.nq >= c->certify_min)
+  if (pgrid && mode == 1 && a.qlist && a.cert && heavy_cloud(c))
   {
     // The leftovers of a large cloud: the host does not know how many there are.  Most of
     // the cloud (the first passes with the shortcut, when hardly any query holds a
@@ -1791,14 +1962,44 @@ static float anchor_reach(const icpx_ctx* c)
 
 // A cloud large enough for its certificates to be checked by k_certify; its passes are long
 // enough, too, for the host to stay closer behind the device (run_catch_up).
+// The host's policy goes by sizes every rank of a job agrees on (in a loop of several ranks
+// all of them must enqueue the same sequence of passes): a shard's size is taken as the
+// job's kept points over its ranks, whichever rank got the odd one.
+static int64_t policy_nq(const icpx_ctx* c)
+{
+  return c->world > 1 ? c->nk / c->world : c->nq;
+}
+// How many queries there are to the mesh's triangles where this rank searches: shards cut
+// from the curve cover one stretch of the surface each at the whole cloud's density, blocks
+// of kept indices are spread over all of it at a fraction.
+static int64_t density_nq(const icpx_ctx* c)
+{
+  return c->curve_shard ? c->nk : policy_nq(c);
+}
 static bool large_cloud(const icpx_ctx* c)
 {
-  return c->certify_min >= 0 && c->nq >= c->certify_min;
+  return c->certify_min >= 0 && policy_nq(c) >= c->certify_min;
+}
+// A cloud whose passes take long enough for the host to stay one pass behind the device in
+// the first passes of a run, so that it knows how the first solve went before it picks the
+// third pass's kernels.
+constexpr int64_t CLOSE_FOLLOW_MIN = 262144;
+// A cloud that gets the large cloud's policy (certificates checked by k_certify, its list
+// straight to the tree kernels, pair certificates, no certificates from the third pass): a
+// large one, and one of some size whose points stay beyond the neighbour lists' reach (a noisy
+// scan: the shortcut settles none of them, whatever the cloud's size; an eighth of sixteen
+// million noisy points took 35.8 ms per registration with the small cloud's policy and 23.3
+// with this one).  `noisy` follows the records, so a clean cloud that merely starts far from
+// its place changes over when it arrives.
+static bool heavy_cloud(const icpx_ctx* c)
+{
+  return large_cloud(c) ||
+    (c->noisy_policy && c->noisy && c->certify_min >= 0 && policy_nq(c) >= CLOSE_FOLLOW_MIN);
 }
 
 // A finished pass's figures, for the shortcut's policy (see prepare_local).
 static void note_pass(icpx_ctx* c, double n, double mean, double fallback, double listed,
-  bool was_local, bool was_listed)
+  bool was_local, bool was_listed, double nq_ref)
 {
   // The shortcut settles a query within half the lists' radius of its triangle: with the
   // mean residual at twice the radius it settles next to none (a noisy scan, or a cloud
@@ -1817,7 +2018,7 @@ static void note_pass(icpx_ctx* c, double n, double mean, double fallback, doubl
     if (c->hopeless_streak >= 2)
       c->direct = true;
   }
-  const bool bad = n > 0.0 && fallback > 0.5 * (double)c->nq && 3.0 * mean > (double)c->nbr_eps;
+  const bool bad = n > 0.0 && fallback > 0.5 * nq_ref && 3.0 * mean > (double)c->nbr_eps;
   c->bad_streak = bad ? c->bad_streak + 1 : 0;
   if (!bad && c->local_holdoff == 0)
     c->probation = false;
@@ -1853,14 +2054,14 @@ static int prepare_local(icpx_ctx* c, bool* use)
     // pass's winners are far from this pass's, and a whole pass of the tree kernel (which
     // re-seeds such queries) is cheaper than a long walk plus the tree for what is left
     c->after_cold = false;
-    if (c->persistent >= 3 && c->nq * 4 >= c->nt)
+    if (c->persistent >= 3 && density_nq(c) * 4 >= c->nt)
       return ICPX_OK;
   }
   if (c->stat_pending && hipEventQuery(c->ev_stat) == hipSuccess)
   {
     c->stat_pending = false;
     note_pass(c, c->h_stat[0], c->h_stat[0] > 0.0 ? c->h_stat[1] / c->h_stat[0] : 0.0,
-      c->h_stat[2], c->h_stat[3], c->stat_local, c->stat_listed);
+      c->h_stat[2], c->h_stat[3], c->stat_local, c->stat_listed, (double)c->nq);
   }
   if (c->local_holdoff > 0)
   {
@@ -1871,7 +2072,7 @@ static int prepare_local(icpx_ctx* c, bool* use)
   // A large cloud that stays beyond the lists' reach does without the shortcut: a pass with
   // certificates to check hands k_certify's list straight to the tree kernels, one without
   // is a whole tree pass (which leaves certificates).  The lists are not even built for it.
-  if (c->noisy && large_cloud(c))
+  if (c->noisy && heavy_cloud(c))
   {
     if (!(c->use_cert && c->certs_live))
       return ICPX_OK;
@@ -1896,9 +2097,25 @@ static void fill_lean(icpx_ctx* c, FinalArgs& f);
 // of one rank, a cloud whose certificates the shortcut itself checks, the default kernels.
 static bool lean_capable(const icpx_ctx* c)
 {
-  return c->use_lean && c->run_active && c->run_fused && !large_cloud(c) && c->use_local == 1 &&
-    c->use_cert && c->persistent == 4 && !c->exhaustive && pick_width(c) == 1 &&
-    finalize_on_matrix_core(c, c->nq);
+  if (!(c->use_lean && c->run_active && (c->run_fused || c->run_shared) && !large_cloud(c) &&
+        c->use_local == 1 && c->use_cert && c->persistent == 4 && !c->exhaustive))
+    return false;
+  // (several ranks: all must answer alike, so the size class goes by policy_nq, and the few
+  // queries more or fewer of some rank must not change it)
+  // (a shard's size is within a chunk of the curve order, 8192 points, of policy_nq)
+  if (c->run_shared)
+    return c->group_width <= 1 && policy_nq(c) > 32768 + 8192 &&
+      finalize_on_matrix_core(c, policy_nq(c) + 8192);
+  return pick_width(c) == 1 && finalize_on_matrix_core(c, c->nq);
+}
+// Whether the pass about to be enqueued is tried as a lean one: the last pass left every
+// certificate up to date, and the last record looked at was of a pass that left next to
+// nothing to the tree kernels (use_lean >= 2, for tests: whatever the record said, so that
+// lean passes fail and are repeated while the cloud still moves).
+static bool lean_wanted(const icpx_ctx* c)
+{
+  return lean_capable(c) && c->lean_base && (c->clean_noted || c->use_lean >= 2) &&
+    c->lean_holdoff == 0 && c->hint_valid;
 }
 
 static int run_search3(icpx_ctx* c)
@@ -1958,7 +2175,7 @@ static int run_search3(icpx_ctx* c)
   // small clouds keep them only where lean passes, which have no k_contested, are to follow)
   // (2: a pair only where a single winner's certificate would be next to nothing; a lean pass
   // lets a single winner through on its certificate alone, a pair it has to weigh)
-  a.pairs = (c->certify_min >= 0 && c->nq >= c->certify_min) ? 1 : lean_capable(c) ? 2 : 0;
+  a.pairs = heavy_cloud(c) ? 1 : lean_capable(c) ? 2 : 0;
   a.setmask = nullptr; // (set below, once the pass's kernels are known)
   a.refill = c->refill_override > 0 ? c->refill_override : (c->hint_valid ? 40 : REFILL3);
   hipStream_t st = c->stream;
@@ -1974,7 +2191,7 @@ static int run_search3(icpx_ctx* c)
   // sparse cloud, is scattered and goes one pooled lane per query
   int mode = c->persistent;
   if (mode == 4)
-    mode = (!use_local && c->nq * 4 >= c->nt) ? 3 : 1;
+    mode = (!use_local && density_nq(c) * 4 >= c->nt) ? 3 : 1;
   // the wavefront walk, the pooled lanes and the shortcut keep certificates; the other
   // variants do not, and a pass of theirs leaves the certificates behind
   // (nor does the wavefront walk on a cold pass and the one after it: those moves outrun
@@ -1982,7 +2199,7 @@ static int run_search3(icpx_ctx* c)
   // nor on the third: measured on 16 M noisy points, the move after it still broke seven
   // eighths of them)
   c->since_cold = c->hint_valid ? c->since_cold + 1 : 0;
-  c->pass_certs = c->use_cert && (mode == 1 || (mode == 3 && c->since_cold >= (large_cloud(c) ? 3 : 2)));
+  c->pass_certs = c->use_cert && (mode == 1 || (mode == 3 && c->since_cold >= (heavy_cloud(c) ? 3 : 2)));
   a.cert = c->pass_certs ? c->d_cert : nullptr;
   // a kernel that checks every query's certificate runs in this pass (the shortcut or
   // k_certify, or the wavefront walk over the whole cloud): it marks the queries that stand
@@ -2013,13 +2230,16 @@ static int run_search3(icpx_ctx* c)
     la.work = nullptr;
     la.work_count = nullptr;
     la.segcap = 0;
-    la.pairs_to_tree = (lean_capable(c) && a.cert && c->heaps[4].built) ? 1 : 0;
+    // (lean passes follow the shortcut's own passes only: k_certify_rest reads the neighbour
+    // lists, which a cloud that goes by the large cloud's policy may never have built)
+    la.pairs_to_tree = (lean_capable(c) && !heavy_cloud(c) && a.cert && c->heaps[4].built &&
+                         c->nbr_state == 1 && c->d_noff && c->d_nbr) ? 1 : 0;
     c->lean_pairs_pass = la.pairs_to_tree != 0;
     unsigned lgrid = grid;
     bool listed = false;
     // a large cloud with certificates from the last pass: those are checked by a light
     // kernel of their own, and the shortcut serves the ones that failed
-    if (a.cert && c->certs_live && a.use_hint && c->certify_min >= 0 && c->nq >= c->certify_min)
+    if (a.cert && c->certs_live && a.use_hint && heavy_cloud(c))
     {
       CertifyArgs ca;
       ca.qpos = c->d_qpos;
@@ -2117,7 +2337,8 @@ static int run_search3(icpx_ctx* c)
   c->hint_valid = true;
   // (what a lean pass can follow: the shortcut checked every certificate and whatever was
   // searched again, here or by the tree kernels, got a new one)
-  c->lean_base = use_local && !c->last_listed && c->pass_certs && mode == 1 && widep != nullptr;
+  c->lean_base = use_local && !c->last_listed && c->pass_certs && mode == 1 && widep != nullptr &&
+    !heavy_cloud(c) && c->nbr_state == 1 && c->d_noff && c->d_nbr;
   return ICPX_OK;
 }
 
@@ -2341,14 +2562,26 @@ static void fill_lean(icpx_ctx* c, FinalArgs& f)
   f.scene_max = c->scene_max;
 }
 
-// A lean pass of one rank's fused loop: the certificate check and the fused sums in one
-// kernel, the reduction and the solve in the other.  Nothing on the host changes but the
-// run's position: the shortcut's policy, the pass counters and the certificates' standing
-// are those of the last full pass.
+// A lean pass: the certificate check and the fused sums in one kernel, then the reduction,
+// with the solve on the same launch (one rank's fused loop) or left to icpx_run_update behind
+// the caller's all-reduce (several ranks: the reduction puts the pass's flag into the sums'
+// spare slot, so that a pass that failed on one rank is dropped by all).  Nothing on the host
+// changes but the run's position: the shortcut's policy, the pass counters and the
+// certificates' standing are those of the last full pass.
 static int enqueue_lean(icpx_ctx* c, int metric, double max_dist, double min_dot, int use_sn,
-  double* dst)
+  double* dst, bool fused)
 {
   hipStream_t st = c->stream;
+  c->last_lean = true;
+  if (!fused && !(c->nq > 0 && c->d_cand && c->d_cert && c->d_counters && pick_width(c) == 1 &&
+                  finalize_on_matrix_core(c, c->nq)))
+  {
+    // (every rank of a job decides alike from the same records; a rank that finds itself
+    // without what a lean pass reads says so, and the pass is repeated in full by all)
+    k_lean_unready<<<1, 64, 0, st>>>(dst, &c->d_state->done, c->nq);
+    LAUNCHCHK();
+    return ICPX_OK;
+  }
   FinalArgs f;
   fill_final(c, f, max_dist, min_dot, use_sn, use_sn || metric == ICPX_METRIC_PLANE_TO_PLANE);
   fill_lean(c, f);
@@ -2365,6 +2598,15 @@ static int enqueue_lean(icpx_ctx* c, int metric, double max_dist, double min_dot
       launch_ev(c, true, k_finalize_mx<1, false, true>, (unsigned)grid, FIN_THREADS, st, f);
     else
       launch_ev(c, true, k_finalize_mx<2, false, true>, (unsigned)grid, FIN_THREADS, st, f);
+  }
+  if (!fused)
+  {
+    // (the certificates and the transform they refer to stay as they are: no cert_ok)
+    k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, &c->d_state->done,
+      c->d_counters, nullptr, c->d_state->T, c->d_state->cert_T, nullptr, 1, c->cap2,
+      &c->d_state->cert_cap2, 1, c->nq, &c->d_state->lean_fail);
+    LAUNCHCHK();
+    return ICPX_OK;
   }
   const icpx_params& p = c->run_p;
   const int slot = (int)(c->run_it & 3);
@@ -2396,28 +2638,26 @@ static int enqueue_lean(icpx_ctx* c, int metric, double max_dist, double min_dot
 // Search + fused sums of one pass, enqueued on the stream; the transform is the one in
 // the device state.  `stat` asks for the pass's {n, sum |s-t|} to be copied to the host
 // behind an event (for callers that do not run the device-resident loop).
+// loop: 0 a pass by itself (icpx_accumulate, icpx_run_enqueue); 1 a pass of one rank's fused
+// loop (the solve rides on the reduction's launch); 2 a pass of a rank's share of a
+// multi-rank loop (icpx_run_advance: the reduction puts the rank's policy figures into the
+// sums' spare slots, the solve comes behind the caller's all-reduce).
 static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, double min_dot,
-  int use_sn, double* dst, bool stat, bool fuse_solve = false)
+  int use_sn, double* dst, bool stat, int loop = 0)
 {
   int rc = prepare_queries(c, step);
   if (rc)
     return rc;
   hipStream_t st = c->stream;
-  if (c->nq == 0)
-  {
-    HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * ICPX_NSUMS, st));
-    return ICPX_OK;
-  }
+  const bool fuse_solve = loop == 1;
   set_cap(c, max_dist);
-  if (fuse_solve)
+  c->last_lean = false;
+  if (loop)
   {
     // A lean pass when the run has settled (see icpx_ctx::use_lean); a full pass must not be
     // enqueued behind lean ones whose records are still out (if one of them failed, this
     // pass's bookkeeping on the host would be of a pass that never ran).
-    // (use_lean == 2, for tests: tried whatever the last record said, so that lean passes
-    // fail and are repeated while the cloud still moves)
-    bool lean = lean_capable(c) && c->lean_base && (c->clean_noted || c->use_lean >= 2) &&
-      c->lean_holdoff == 0 && c->hint_valid && c->d_cand && c->d_cert;
+    bool lean = lean_wanted(c);
     if (!lean && c->lean_unnoted > 0)
     {
       const int64_t it0 = c->run_it;
@@ -2427,13 +2667,17 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
       if (c->run_done_known)
         return ICPX_OK;
       if (c->run_it == it0)
-        lean = lean_capable(c) && c->lean_base && (c->clean_noted || c->use_lean >= 2) &&
-          c->lean_holdoff == 0;
+        lean = lean_wanted(c);
     }
     if (lean)
-      return enqueue_lean(c, metric, max_dist, min_dot, use_sn, dst);
+      return enqueue_lean(c, metric, max_dist, min_dot, use_sn, dst, fuse_solve);
     if (c->lean_holdoff > 0)
       c->lean_holdoff--;
+  }
+  if (c->nq == 0)
+  {
+    HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * ICPX_NSUMS, st));
+    return ICPX_OK;
   }
   rc = run_search(c);
   if (rc)
@@ -2476,7 +2720,8 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
   else
     k_reduce_partials<<<ICPX_NSUMS, 64, 0, st>>>(c->d_partials, grid, dst, &c->d_state->done,
       c->d_counters, want_stat ? c->d_stat : nullptr, c->d_state->T, c->d_state->cert_T,
-      &c->d_state->cert_ok, cert_mode, c->cap2, &c->d_state->cert_cap2);
+      &c->d_state->cert_ok, cert_mode, c->cap2, &c->d_state->cert_cap2, loop == 2 ? 1 : 0, c->nq,
+      nullptr);
   LAUNCHCHK();
   if (c->d_counters)
     c->counters_clean = true;
@@ -2534,14 +2779,22 @@ extern "C" int icpx_accumulate_static(icpx_ctx* c, int metric, const double T[16
   if (step < 1)
     return fail(ICPX_E_INVALID, "step must be >= 1");
   const int64_t nk = (c->np + step - 1) / step;
-  const int64_t k0 = nk * c->rank / c->world, k1 = nk * (c->rank + 1) / c->world;
-  const int64_t nq = k1 - k0;
+  int64_t k0 = 0, nq = 0;
+  ShardMap map;
+  const bool curve = shard_extent(c, nk, &k0, &nq, &map);
   if (nq > STATIC_MAX_QUERIES)
     return fail(ICPX_E_INVALID,
       "icpx_accumulate_static: %lld kept source points, the static scratch holds %lld at most "
       "(use icpx_accumulate, or a larger step)",
       (long long)nq, (long long)STATIC_MAX_QUERIES);
-  if (rs_scratch_words(nq) > (int64_t)ST_SORT_WORDS)
+  // (shards cut from the curve order: all kept points of the job are ordered here, in the
+  // same scratch)
+  if (curve && nk > STATIC_MAX_QUERIES)
+    return fail(ICPX_E_INVALID,
+      "icpx_accumulate_static: %lld kept source points in the job, the static scratch orders "
+      "%lld at most (use icpx_accumulate, or a larger step)",
+      (long long)nk, (long long)STATIC_MAX_QUERIES);
+  if (rs_scratch_words(curve ? nk : nq) > (int64_t)ST_SORT_WORDS)
     return fail(ICPX_E_INVALID, "icpx_accumulate_static: sort scratch too small");
   if (c->device >= ST_MAX_DEVICES || !g_scratch_ptr[c->device])
     return fail(ICPX_E_INVALID, "icpx_accumulate_static: no scratch address for device %d",
@@ -2580,10 +2833,21 @@ extern "C" int icpx_accumulate_static(icpx_ctx* c, int metric, const double T[16
   // the array keeps the last call's contents: everything read below is written first (the
   // sort clears its own histograms, k_gather_queries writes every query's slot, hints start
   // at -1, every finalize block writes its partial)
-  k_morton_points<<<nblk(nq, 256), 256, 0, st>>>(c->d_src, k0, step, nq, c->box, ka, va);
-  const int which = radix_sort_pairs(ka, va, kb, vb, nq, 63, sortscr, st);
-  k_gather_queries<<<nblk(nq, 256), 256, 0, st>>>(
-    c->d_src, c->d_srcn, which ? vb : va, k0, step, nq, qpos, qsn, qk, hint);
+  if (curve)
+  {
+    k_morton_points<<<nblk(nk, 256), 256, 0, st>>>(c->d_src, 0, step, nk, c->box, ka, va, c->query_curve);
+    const int which = radix_sort_pairs(ka, va, kb, vb, nk, 63, sortscr, st);
+    HIPCHK(hipMemsetAsync(qk, 0, sizeof(int32_t) * nq, st)); // (slots matter to rows only)
+    k_gather_queries_curve<<<nblk(nq, 256), 256, 0, st>>>(
+      c->d_src, c->d_srcn, (which ? vb : va) + k0, map, step, nq, qpos, qsn, hint);
+  }
+  else
+  {
+    k_morton_points<<<nblk(nq, 256), 256, 0, st>>>(c->d_src, k0, step, nq, c->box, ka, va, c->query_curve);
+    const int which = radix_sort_pairs(ka, va, kb, vb, nq, 63, sortscr, st);
+    k_gather_queries<<<nblk(nq, 256), 256, 0, st>>>(
+      c->d_src, c->d_srcn, which ? vb : va, k0, step, nq, qpos, qsn, qk, hint);
+  }
   set_cap(c, max_dist);
   Search2Args a;
   a.qpos = qpos;
@@ -2692,6 +2956,7 @@ extern "C" int icpx_correspond(icpx_ctx* c, const double T[16], int64_t step, do
   CompactArgs ca;
   ca.nq = nq;
   ca.k0 = c->k0;
+  ca.kglobal = c->curve_shard ? c->d_kglobal : nullptr;
   ca.step = step;
   ca.flag = c->r_flag;
   ca.pos = c->r_pos;
@@ -2821,6 +3086,7 @@ extern "C" int icpx_correspond_f64(icpx_ctx* c, const double T[16], int64_t step
   Compact64Args ca;
   ca.nq = nq;
   ca.k0 = c->k0;
+  ca.kglobal = c->curve_shard ? c->d_kglobal : nullptr;
   ca.step = step;
   ca.flag = c->r_flag;
   ca.pos = c->r_pos;
@@ -3002,6 +3268,8 @@ extern "C" int icpx_run_begin(icpx_ctx* c, const icpx_params* p)
   c->holdoff_len = 8;
   c->probation = false;
   c->run_fused = false;
+  c->run_shared = false;
+  c->last_lean = false;
   c->lean_base = false;
   c->clean_noted = false;
   c->lean_unnoted = 0;
@@ -3076,7 +3344,7 @@ static int run_catch_up(icpx_ctx* c, int lag_override)
   // (lag_override 0: everything enqueued so far, for a caller that must know how the lean
   // passes still out have ended)
   const int lag = lag_override >= 0 ? lag_override + 1
-                                    : (large_cloud(c) && c->since_cold <= 3) ? 1 : 2;
+                                    : (policy_nq(c) >= CLOSE_FOLLOW_MIN && c->since_cold <= 3) ? 1 : 2;
   while (c->run_noted + lag <= c->run_it)
   {
     const int slot = (int)(c->run_noted & 3);
@@ -3113,20 +3381,23 @@ static int run_catch_up(icpx_ctx* c, int lag_override)
           r.iters, r.done, r.n, r.mean, r.fallback, r.contested, r.listed, (int)c->lean_base,
           c->lean_holdoff);
     }
+    // (several ranks: the record's counts are the job's, and so is the number they are held
+    // against)
+    const int64_t nq_rec = c->run_shared ? (int64_t)r.nq_total : c->nq;
     // (the few queries that pass left to the tree kernels were given certificates by them)
     c->clean_noted = (c->pass_lean[slot] || (c->pass_local[slot] && !c->pass_listed[slot])) &&
-      (int64_t)r.fallback + (int64_t)r.contested <= std::max<int64_t>(16, c->nq >> 13);
+      (int64_t)r.fallback + (int64_t)r.contested <= std::max<int64_t>(16, nq_rec >> 13);
     if (r.done)
       c->run_done_known = true;
     note_pass(c, r.n, r.mean, (double)r.fallback, (double)r.listed, c->pass_local[slot],
-      c->pass_listed[slot]);
+      c->pass_listed[slot], (double)nq_rec);
     tally_split(c, slot);
     c->run_noted++;
   }
   return ICPX_OK;
 }
 
-static int run_enqueue_impl(icpx_ctx* c, double* sums_device, int* done_out, bool fuse_solve)
+static int run_enqueue_impl(icpx_ctx* c, double* sums_device, int* done_out, int loop)
 {
   if (!c || !c->run_active)
     return fail(ICPX_E_INVALID, "icpx_run_enqueue: no run in progress (call icpx_run_begin)");
@@ -3141,12 +3412,49 @@ static int run_enqueue_impl(icpx_ctx* c, double* sums_device, int* done_out, boo
   const icpx_params& p = c->run_p;
   return enqueue_pass(c, p.metric, c->run_step, p.max_distance, p.min_normal_dot,
     p.metric == ICPX_METRIC_PLANE_TO_PLANE ? (p.rotate_source_normals ? 2 : 1) : 0,
-    sums_device ? sums_device : c->d_sums, false, fuse_solve);
+    sums_device ? sums_device : c->d_sums, false, loop);
 }
 
 extern "C" int icpx_run_enqueue(icpx_ctx* c, double* sums_device, int* done_out)
 {
-  return run_enqueue_impl(c, sums_device, done_out, false);
+  if (c && c->run_shared)
+    return fail(ICPX_E_INVALID, "icpx_run_enqueue: this run is driven by icpx_run_advance");
+  return run_enqueue_impl(c, sums_device, done_out, 0);
+}
+
+extern "C" int icpx_run_advance(icpx_ctx* c, double* sums_device, int* more_out)
+{
+  if (!c || !c->run_active || !more_out)
+    return fail(ICPX_E_INVALID, "icpx_run_advance: no run in progress (call icpx_run_begin), or more_out is null");
+  if (!sums_device)
+    return fail(ICPX_E_INVALID, "icpx_run_advance: sums_device is null");
+  if (!c->run_shared && c->run_it != 0)
+    return fail(ICPX_E_INVALID, "icpx_run_advance: this run is driven by icpx_run_enqueue");
+  *more_out = 0;
+  HIPCHK(hipSetDevice(c->device));
+  c->run_shared = true;
+  const icpx_params& p = c->run_p;
+  // (c->run_it is the run's position: a failed lean pass takes it back)
+  while (!c->run_done_known && c->run_it >= p.max_iterations)
+  {
+    if (c->lean_unnoted == 0)
+      return ICPX_OK;
+    const int rc = run_catch_up(c, 0); // how did the lean passes still out end?
+    if (rc)
+      return rc;
+  }
+  if (c->run_done_known)
+    return ICPX_OK;
+  int done = 0;
+  int rc = run_enqueue_impl(c, sums_device, &done, 2);
+  if (rc)
+    return rc;
+  // (nothing was enqueued when the records read on the way said that the run is over; or when
+  // they took the position back and left it at the end again: the next call sorts that out)
+  if (done || c->run_done_known)
+    return ICPX_OK;
+  *more_out = 1;
+  return ICPX_OK;
 }
 
 extern "C" int icpx_run_update(icpx_ctx* c, const double* sums_device)
@@ -3163,7 +3471,7 @@ extern "C" int icpx_run_update(icpx_ctx* c, const double* sums_device)
 #define ICPX_SOLVE(M)                                                                            \
   k_solve<M><<<1, 64, 0, st>>>(c->d_state, sums_device ? sums_device : c->d_sums, c->origin[0],  \
     c->origin[1], c->origin[2], p.check_mean_distance, p.max_mean_distance, c->d_counters,       \
-    c->d_rec + slot, seq, anchor_rmax(c), anchor_reach(c))
+    c->d_rec + slot, seq, anchor_rmax(c), anchor_reach(c), c->run_shared ? 1 : 0)
   if (p.metric == 0)
     ICPX_SOLVE(0);
   else if (p.metric == 1)
@@ -3173,9 +3481,16 @@ extern "C" int icpx_run_update(icpx_ctx* c, const double* sums_device)
 #undef ICPX_SOLVE
   LAUNCHCHK();
   c->slot_seq[slot] = c->rec_seq;
-  c->pass_local[slot] = c->last_local;
-  c->pass_listed[slot] = c->last_listed;
-  c->pass_split[slot] = c->last_split;
+  c->pass_local[slot] = c->last_lean ? false : c->last_local;
+  c->pass_listed[slot] = c->last_lean ? false : c->last_listed;
+  c->pass_split[slot] = c->last_lean ? false : c->last_split;
+  c->pass_lean[slot] = c->last_lean;
+  if (c->last_lean)
+  {
+    c->lean_unnoted++;
+    c->lean_passes++;
+  }
+  c->last_lean = false;
   c->run_it++;
   return ICPX_OK;
 }
@@ -3229,7 +3544,7 @@ extern "C" int icpx_run(icpx_ctx* c, const icpx_params* p, double T_out[16], int
         continue;
       }
       int done = 0;
-      rc = run_enqueue_impl(c, nullptr, &done, fuse);
+      rc = run_enqueue_impl(c, nullptr, &done, fuse ? 1 : 0);
       if (rc || done)
         break;
       if (!fuse)

@@ -19,6 +19,7 @@
 // a subtree is skipped only when the fp64 distance to its (outward-rounded)
 // box exceeds the best dist2 so far, so the traversal order cannot change it.
 #pragma once
+#include "state.hpp"
 #include "../../include/icpx.h"
 #include "bvh.hpp"
 #include "cert.hpp"
@@ -856,11 +857,23 @@ __device__ __forceinline__ bool reduce_partials_body(
   const double* __restrict__ partials, int nblocks, double* __restrict__ sums,
   const int32_t* __restrict__ stop, uint32_t* __restrict__ counters, double* __restrict__ stat,
   const double* __restrict__ T, double* __restrict__ cert_T, int32_t* __restrict__ cert_ok,
-  int cert_mode, double cap2 = 0.0, double* __restrict__ cert_cap2 = nullptr)
+  int cert_mode, double cap2 = 0.0, double* __restrict__ cert_cap2 = nullptr, int share = 0,
+  int64_t nq = 0, const int32_t* __restrict__ lean_fail = nullptr)
 {
   if (stop && *stop)
     return false; // the pass did not run
   const int i = blockIdx.x, l = threadIdx.x;
+  // share: the loop of several ranks.  The spare slots of the vector carry this rank's policy
+  // figures through the all-reduce (state.hpp: SLOT_*): the query count and the lean pass's
+  // flag from their own blocks, the three counts from block 0, which moves the counters.
+  if (share && i >= SLOT_NQ)
+  {
+    if (l == 0 && i == SLOT_NQ)
+      sums[i] = (double)nq;
+    if (l == 0 && i == SLOT_LEANFAIL)
+      sums[i] = (lean_fail && *reinterpret_cast<const volatile int32_t*>(lean_fail) != 0) ? 1.0 : 0.0;
+    return true;
+  }
   if (cert_ok && i == 1)
   {
     // (an anchored pass left the certificates as they were: so stays their transform)
@@ -873,15 +886,24 @@ __device__ __forceinline__ bool reduce_partials_body(
         *cert_cap2 = cap2;
     }
   }
+  uint32_t old = 0u;
   if (counters && i == 0 && l < 4)
   {
     // the search kernels' four pass counters move up for whoever wants to look at them,
     // and are left at zero for the next pass
-    const uint32_t old = counters[l];
+    old = counters[l];
     counters[4 + l] = old;
     counters[l] = 0u;
     if (stat && l == 3)
       stat[2] = (double)old; // shortcut fallbacks of this pass
+  }
+  if (share && i == 0)
+  {
+    const uint32_t overflows = (uint32_t)__shfl((int)old, 1, 64);
+    if (l == 0)
+      sums[SLOT_CONTESTED] = (double)old + (double)overflows; // (ties + overflows)
+    if (l == 3)
+      sums[SLOT_FALLBACK] = (double)old;
   }
   if (counters && i == 0)
   {
@@ -900,8 +922,12 @@ __device__ __forceinline__ bool reduce_partials_body(
       counters[8] = len;
       if (stat)
         stat[3] = (double)len;
+      if (share)
+        sums[SLOT_LISTED] = (double)len;
     }
   }
+  if (share && !counters && i == 0 && l == 0)
+    sums[SLOT_LISTED] = 0.0;
   if (stat && !counters && i == 0 && l == 0)
   {
     stat[2] = 0.0;
@@ -930,10 +956,23 @@ __global__ __launch_bounds__(64) void k_reduce_partials(
   const double* __restrict__ partials, int nblocks, double* __restrict__ sums,
   const int32_t* __restrict__ stop, uint32_t* __restrict__ counters, double* __restrict__ stat,
   const double* __restrict__ T, double* __restrict__ cert_T, int32_t* __restrict__ cert_ok,
-  int cert_mode, double cap2, double* __restrict__ cert_cap2)
+  int cert_mode, double cap2, double* __restrict__ cert_cap2, int share = 0, int64_t nq = 0,
+  const int32_t* __restrict__ lean_fail = nullptr)
 {
   (void)reduce_partials_body(partials, nblocks, sums, stop, counters, stat, T, cert_T, cert_ok,
-    cert_mode, cap2, cert_cap2);
+    cert_mode, cap2, cert_cap2, share, nq, lean_fail);
+}
+
+// A rank of a multi-rank loop that was to run a lean pass and cannot (it holds no certificates
+// to check): its sums are zero and its flag says that the pass has failed, so that every rank
+// drops the pass and repeats it in full.
+__global__ void k_lean_unready(double* __restrict__ sums, const int32_t* __restrict__ stop, int64_t nq)
+{
+  if (*stop)
+    return;
+  const int l = threadIdx.x;
+  if (l < ICPX_NSUMS)
+    sums[l] = l == SLOT_LEANFAIL ? 1.0 : l == SLOT_NQ ? (double)nq : 0.0;
 }
 
 // Query set-up: gather the kept points (and normals) of the shard into Morton order.
@@ -960,10 +999,67 @@ __global__ void k_gather_queries(const float* __restrict__ xyz, const float* __r
   hint[p] = -1;
 }
 
+// A shard cut from the curve order of all kept points (icpx_set_shard): `order` holds the
+// kept indices of all of them in that order.  Rows come out by ascending source index, so
+// every query also needs its rank among the shard's kept indices: they are sorted (key = kept
+// index, value = position), and k_shard_slots turns the sorted pairs into slot -> kept index
+// and position -> slot.
+// Which positions of the curve order are a shard's: chunks of `chunk` consecutive positions
+// are dealt out to the ranks in turn (rank r has chunks r, r + world, ...; chunk >= the
+// number of kept points / world makes that one range per rank).  Query j of the shard:
+struct ShardMap
+{
+  int64_t chunk;
+  int rank, world;
+  __device__ __host__ int64_t pos(int64_t j) const
+  {
+    return ((int64_t)rank + (j / chunk) * world) * chunk + j % chunk;
+  }
+};
+__global__ void k_shard_keys(const uint32_t* __restrict__ order, ShardMap m, int64_t nq,
+  uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nq)
+    return;
+  keys[p] = order[m.pos(p)];
+  vals[p] = (uint32_t)p;
+}
+__global__ void k_shard_slots(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+  int64_t nq, int32_t* __restrict__ kglobal, int32_t* __restrict__ qk)
+{
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nq)
+    return;
+  kglobal[r] = (int32_t)keys[r];
+  qk[vals[r]] = (int32_t)r;
+}
+// ... and the gather for such a shard (qk is already filled in).
+__global__ void k_gather_queries_curve(const float* __restrict__ xyz, const float* __restrict__ nrm,
+  const uint32_t* __restrict__ order, ShardMap m, int64_t step, int64_t nq,
+  float* __restrict__ qpos, float* __restrict__ qsn, int32_t* __restrict__ hint)
+{
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nq)
+    return;
+  int64_t i = (int64_t)order[m.pos(p)] * step;
+  qpos[3 * p] = xyz[3 * i];
+  qpos[3 * p + 1] = xyz[3 * i + 1];
+  qpos[3 * p + 2] = xyz[3 * i + 2];
+  if (nrm)
+  {
+    qsn[3 * p] = nrm[3 * i];
+    qsn[3 * p + 1] = nrm[3 * i + 1];
+    qsn[3 * p + 2] = nrm[3 * i + 2];
+  }
+  hint[p] = -1;
+}
+
 // K8: accepted rows, already in ascending kept-index order, packed to the front.
 struct CompactArgs
 {
   int64_t nq, k0, step;
+  const int32_t* kglobal; // slot -> kept index of a shard that is not a block of them (or null)
   const uint32_t* flag;
   const uint32_t* pos; // exclusive scan of flag
   const float *origin, *onormal, *closest, *normal;
@@ -991,7 +1087,7 @@ __global__ void k_compact_rows(CompactArgs a)
   }
   a.d_cell[r] = a.cell[k];
   a.d_dist[r] = a.dist[k];
-  a.d_index[r] = (a.k0 + k) * a.step;
+  a.d_index[r] = (a.kglobal ? (int64_t)a.kglobal[k] : a.k0 + k) * a.step;
 }
 
 } // namespace icpx

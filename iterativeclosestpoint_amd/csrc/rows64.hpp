@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void k_rows64(Rows64Args a)
 struct Compact64Args
 {
   int64_t nq, k0, step;
+  const int32_t* kglobal; // slot -> kept index of a shard that is not a block of them (or null)
   const uint32_t* flag;
   const uint32_t* pos; // exclusive scan of flag
   const double *origin, *closest, *normal, *dist;
@@ -113,7 +114,7 @@ __global__ void k_compact_rows64(Compact64Args a)
   }
   a.d_cell[r] = a.cell[k];
   a.d_dist[r] = a.dist[k];
-  a.d_index[r] = (a.k0 + k) * a.step;
+  a.d_index[r] = (a.kglobal ? (int64_t)a.kglobal[k] : a.k0 + k) * a.step;
 }
 
 } // namespace icpx

@@ -624,6 +624,9 @@ __device__ __forceinline__ void search3_body(const Search3Args& a, unsigned bloc
 // development build only: totals over all queries of {node visits, leaves screened, visits that rejected both children,
 // triangle screens, loop iterations (per wavefront), refills}
 __device__ unsigned long long g_stats[8];
+// ... and of the wavefront walk's batches: {largest number of node steps of one batch, longest
+// batch in ticks of the 100 MHz clock, ticks of all batches together, batches}
+__device__ unsigned long long g_stats_batch[4 + 32 + 1]; // (+ where the longest batch starts) // (+ batches and their ticks by node steps / 128)
 #define STAT(i, v) st_##i += (v)
 #else
 #define STAT(i, v)
@@ -1155,6 +1158,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     }
     if (!got)
       break;
+#ifdef ICPX_STATS
+    const unsigned long long bt0 = wall_clock64(), bs0 = st_0;
+#endif
     const int64_t idx = (int64_t)base + lane;
     bool active = idx < total;
     const int64_t q = active ? (a.qlist ? (int64_t)a.qlist[idx] : idx) : 0;
@@ -1622,6 +1628,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         a.ovf_list[ob + __popcll(mo & lt)] = (uint32_t)q;
       }
     }
+#ifdef ICPX_STATS
+    if (lane == 0)
+    {
+      const unsigned long long dt = wall_clock64() - bt0;
+      if (atomicMax(&g_stats_batch[0], st_0 - bs0) < st_0 - bs0)
+        g_stats_batch[36] = base; // (a race between two record holders is harmless)
+      atomicMax(&g_stats_batch[1], dt);
+      atomicAdd(&g_stats_batch[2], dt);
+      atomicAdd(&g_stats_batch[3], 1ull);
+      const int bucket = (int)min((st_0 - bs0) / 128ull, 15ull);
+      atomicAdd(&g_stats_batch[4 + bucket], 1ull);
+      atomicAdd(&g_stats_batch[20 + bucket], dt);
+    }
+#endif
   }
 #ifdef ICPX_STATS
   atomicAdd(&g_stats[0], st_0);

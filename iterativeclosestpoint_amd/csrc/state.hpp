@@ -37,8 +37,22 @@ struct RunRecord
   uint32_t seq; // the solve's serial number, stored after the rest: the host waits for it
   uint32_t listed; // queries on k_certify's list of failed certificates in that pass (0: no such list)
   uint32_t contested; // queries that pass left to k_contested through the tie and overflow lists
-  uint32_t pad_;
+  uint32_t nq_total;  // queries those three counts are of: this rank's, or (a loop whose sums are
+                      // all-reduced with the figures riding in the spare slots) every rank's
 };
+// The spare slots of the ICPX_NSUMS vector (no metric has more than 35 sums).  In the loop of
+// several ranks (icpx_run_advance) the reduction puts this rank's policy figures there, the
+// all-reduce adds them up with the sums, and every rank's solve reads the job's totals: all
+// ranks see the same records, decide alike and enqueue the same sequence of passes.
+constexpr int SLOT_NQ = 35;        // queries searched
+constexpr int SLOT_FALLBACK = 36;  // ... left to the tree walk by the shortcut
+constexpr int SLOT_LISTED = 37;    // ... on k_certify's list
+constexpr int SLOT_CONTESTED = 38; // ... left to k_contested's lists
+constexpr int SLOT_LEANFAIL = 39;  // ranks whose lean pass met a query it could not answer
+__device__ __host__ inline uint32_t slot_count(double v)
+{
+  return v > 0.0 ? (v < 4294967295.0 ? (uint32_t)v : 0xffffffffu) : 0u;
+}
 // One iteration's solve and transform update in a single GPU thread: the body of the
 // loop in vtkICP::InternalUpdate after the correspondence filter (ICP/vtkICP.cxx:218-245),
 // and the iteration's record for the host, written straight to pinned host memory, where
@@ -51,7 +65,7 @@ struct RunRecord
 __device__ inline void solve_and_publish(RunState* s, const double* __restrict__ sums, int metric,
   const double* origin, int check_mean, double max_mean, bool ran, uint32_t fallback_now,
   uint32_t listed_now, uint32_t contested_now, RunRecord* rec, uint32_t seq, float src_rmax = 0.f,
-  float anchor_reach = 0.f)
+  float anchor_reach = 0.f, uint32_t nq_total = 0u)
 {
   double Tm[16];
 #pragma unroll
@@ -124,6 +138,7 @@ __device__ inline void solve_and_publish(RunState* s, const double* __restrict__
   rec->fallback = fallback;
   rec->listed = ran ? listed_now : 0u;
   rec->contested = ran ? contested_now : 0u;
+  rec->nq_total = nq_total;
   __threadfence_system();
   *reinterpret_cast<volatile uint32_t*>(&rec->seq) = seq;
 }

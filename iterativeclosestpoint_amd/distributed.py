@@ -17,8 +17,27 @@ from .vtkicp import icp_loop
 
 
 def shard_bounds(n_kept, rank, world):
-    """Kept-index block [k0, k1) of `rank`; the same split icpx_set_shard applies."""
+    """Block [k0, k1) of `rank` when n_kept items are cut into `world` equal blocks in their
+    own order (icpx_set_shard's split with shards by blocks of kept indices, and what a host
+    loop over its own arrays uses)."""
     return n_kept * rank // world, n_kept * (rank + 1) // world
+
+
+def shard_size(n_kept, rank, world):
+    """Number of kept points icpx_set_shard(rank, world) gives this rank: chunks of the kept
+    points' order along the space-filling curve (8192 points; halved while a rank would have
+    fewer than eight) are dealt out to the ranks in turn."""
+    if world == 1:
+        return n_kept
+    chunk = 8192
+    while chunk > 1 and n_kept < 8 * world * chunk:
+        chunk //= 2
+    nchunks = (n_kept + chunk - 1) // chunk
+    mine = (nchunks - rank + world - 1) // world if rank < nchunks else 0
+    n = mine * chunk
+    if mine > 0 and (nchunks - 1) % world == rank and n_kept % chunk:
+        n -= chunk - n_kept % chunk
+    return n
 
 
 def all_reduce_device(t, group=None):
@@ -107,48 +126,52 @@ class ShardedICP:
 
     def _local_failure(self, exc, multi):
         """A rank whose library call failed must not leave the others waiting in the
-        all-reduce: close the run, and in a multi-rank job end this process (the peers'
-        collectives then fail instead of blocking for ever)."""
+        all-reduce: in a multi-rank job this process ends (the peers' collectives then fail
+        instead of blocking for ever), and it does so before anything that waits for the
+        stream, where a collective that cannot complete may be queued.  A single rank closes
+        the run."""
         import os
         import sys
-        try:
-            self.ctx.run_end()          # clears the run; waits for what was enqueued
-        except Exception:
-            pass
         if multi and self.exit_on_error:
             sys.stderr.write("ShardedICP rank %d: %s; leaving the job\n" % (self.rank, exc))
             sys.stderr.flush()
             os._exit(70)
+        try:
+            self.ctx.run_end()          # clears the run; waits for what was enqueued
+        except Exception:
+            pass
 
-    def run_device(self, params, force_collective=False):
+    def run_device(self, params, force_collective=False, emulate=False):
         """The whole loop without a host round trip per iteration: search and sums on the
         GPU, all-reduce of the 40 sums on the device (stream-ordered, RCCL), solve and
         transform update on the device.  Needs the device all-reduce buffer (the default).
         Returns (T 4x4, iterations, mean_distance, status), the same on every rank.
+        The library keeps the loop's position (icpx_run_advance): a settled pass tried as a
+        lean one that some rank could not answer is dropped by all and repeated.
         force_collective runs the all-reduce even in a one-rank group (a test of the stream
-        ordering between the library's kernels and the collective)."""
+        ordering between the library's kernels and the collective); emulate runs one rank's
+        share of a multi-rank loop by itself, without a process group (measurements of what
+        a rank of an N-rank job does: the registration is then of this shard alone)."""
         import torch
         import torch.distributed as dist
 
         assert self.sums_dev is not None, "run_device needs use_device_allreduce=True"
-        multi = dist.is_available() and dist.is_initialized() and \
-            (dist.get_world_size(self.group) > 1 or force_collective)
-        if not multi:
+        grouped = dist.is_available() and dist.is_initialized()
+        multi = grouped and (dist.get_world_size(self.group) > 1 or force_collective)
+        if not multi and not emulate:
             # one rank: the library's own loop (the solve rides on the reduction's launch)
             with torch.cuda.stream(self.stream):
                 return self.ctx.run(params)
         ptr = self.sums_dev.data_ptr()
-        self.ctx.run_begin(params)
         try:
+            self.ctx.run_begin(params)
             with torch.cuda.stream(self.stream):
-                for _ in range(params.max_iterations):
-                    if self.ctx.run_enqueue(ptr):
-                        break
+                while self.ctx.run_advance(ptr):
                     if multi:
                         all_reduce_device(self.sums_dev, self.group)
                     self.ctx.run_update(ptr)
         except BaseException as exc:
-            self._local_failure(exc, dist.get_world_size(self.group) > 1)
+            self._local_failure(exc, grouped and dist.get_world_size(self.group) > 1)
             raise
         return self.ctx.run_end()
 

@@ -25,7 +25,7 @@ SYMBOLS = (
     "icpx_synchronize", "icpx_set_target", "icpx_set_source", "icpx_set_shard", "icpx_get_origin",
     "icpx_accumulate", "icpx_accumulate_static", "icpx_correspond", "icpx_correspond_f64", "icpx_solve", "icpx_default_params",
     "icpx_set_allreduce", "icpx_run",
-    "icpx_run_begin", "icpx_run_enqueue", "icpx_run_update", "icpx_run_end",
+    "icpx_run_begin", "icpx_run_enqueue", "icpx_run_advance", "icpx_run_update", "icpx_run_end",
     "icpx_point_normals", "icpx_intersect_lines",
 )
 # ... and in include/icpx_dev.h (kernel variants, diagnostics, timing)
@@ -33,7 +33,8 @@ DEV_SYMBOLS = (
     "icpx_last_build_seconds", "icpx_set_group_width", "icpx_reset_hints", "icpx_set_timing",
     "icpx_get_timing", "icpx_get_pass_timings", "icpx_set_exhaustive", "icpx_set_leaf_size",
     "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local", "icpx_set_refill",
-    "icpx_set_finalize", "icpx_set_lean", "icpx_set_anchor",
+    "icpx_set_finalize", "icpx_set_lean", "icpx_set_anchor", "icpx_set_shard_order",
+    "icpx_set_certify_min", "icpx_set_wave_blocks", "icpx_set_query_curve", "icpx_set_noisy_policy",
 )
 
 
@@ -91,7 +92,13 @@ def load():
                              C.POINTER(ci)]
     lib.icpx_run_begin.argtypes = [vp, C.POINTER(Params)]
     lib.icpx_run_enqueue.argtypes = [vp, vp, C.POINTER(ci)]
+    lib.icpx_run_advance.argtypes = [vp, vp, C.POINTER(ci)]
     lib.icpx_run_update.argtypes = [vp, vp]
+    lib.icpx_set_shard_order.argtypes = [vp, ci]
+    lib.icpx_set_certify_min.argtypes = [vp, i64]
+    lib.icpx_set_wave_blocks.argtypes = [vp, ci]
+    lib.icpx_set_query_curve.argtypes = [vp, ci]
+    lib.icpx_set_noisy_policy.argtypes = [vp, ci]
     lib.icpx_run_end.argtypes = [vp, vp, C.POINTER(ci), C.POINTER(dbl), C.POINTER(ci)]
     lib.icpx_last_build_seconds.argtypes = [vp]
     lib.icpx_last_build_seconds.restype = dbl
@@ -316,6 +323,23 @@ class Context:
     def set_shard(self, rank, world):
         _chk(load().icpx_set_shard(self._h, int(rank), int(world)))
 
+    def set_shard_order(self, order):
+        """1 (default): shards are ranges of the kept points' order along the space-filling
+        curve; 0: blocks of consecutive kept indices."""
+        _chk(load().icpx_set_shard_order(self._h, int(order)))
+
+    def set_wave_blocks(self, blocks_per_cu):
+        _chk(load().icpx_set_wave_blocks(self._h, int(blocks_per_cu)))
+
+    def set_noisy_policy(self, enable):
+        _chk(load().icpx_set_noisy_policy(self._h, int(enable)))
+
+    def set_query_curve(self, hilbert):
+        _chk(load().icpx_set_query_curve(self._h, int(hilbert)))
+
+    def set_certify_min(self, queries):
+        _chk(load().icpx_set_certify_min(self._h, int(queries)))
+
     @property
     def origin(self):
         o = np.zeros(3)
@@ -429,6 +453,13 @@ class Context:
         _chk(load().icpx_run_enqueue(self._h, C.c_void_p(device_ptr) if device_ptr else None,
                                      C.byref(done)))
         return bool(done.value)
+
+    def run_advance(self, device_ptr):
+        """Enqueue the next pass of a loop whose position the library keeps (several ranks:
+        all-reduce the sums at `device_ptr`, then run_update).  False when the run is over."""
+        more = C.c_int(0)
+        _chk(load().icpx_run_advance(self._h, C.c_void_p(device_ptr), C.byref(more)))
+        return bool(more.value)
 
     def run_update(self, device_ptr=None):
         """Enqueue the solve + transform update of the iteration on the (reduced) sums."""
