@@ -2585,7 +2585,9 @@ static int enqueue_lean(icpx_ctx* c, int metric, double max_dist, double min_dot
   FinalArgs f;
   fill_final(c, f, max_dist, min_dot, use_sn, use_sn || metric == ICPX_METRIC_PLANE_TO_PLANE);
   fill_lean(c, f);
-  f.lean_inject = (c->use_lean == 3 && c->lean_passes % 3 == 1) ? 1 : 0;
+  // (tests: every third lean pass is made to fail, on the even ranks of a job only, so that
+  // the odd ones learn of it through the all-reduce)
+  f.lean_inject = (c->use_lean == 3 && c->lean_passes % 3 == 1 && c->rank % 2 == 0) ? 1 : 0;
   const int grid = finalize_grid(c, c->nq);
   {
     // (timed as a search pass of kind 2: the one kernel is the pass's first and last)

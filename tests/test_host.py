@@ -11,7 +11,7 @@ import pytest
 
 from helpers import rel_err, sums_from_rows
 from iterativeclosestpoint_amd import icpx, synth
-from iterativeclosestpoint_amd.distributed import shard_bounds
+from iterativeclosestpoint_amd.distributed import shard_bounds, shard_size
 from iterativeclosestpoint_amd.vtkicp import icp_loop, vtkICP, vtkPolyData
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -166,6 +166,22 @@ def test_shard_bounds_cover_everything():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(k1 - k0 for k0, k1 in b) - min(k1 - k0 for k0, k1 in b) <= 1
+
+
+def test_shard_sizes_cover_everything():
+    """The mirror of icpx_set_shard's split (chunks of the curve order dealt out in turn): the
+    shards hold every kept point once, differ by a chunk at most, and a rank has at least eight
+    chunks wherever there are points enough."""
+    for n in (0, 1, 7, 8, 100, 103, 50_001, 1_000_000, 16_000_000):
+        for w in (1, 2, 3, 4, 8):
+            sizes = [shard_size(n, r, w) for r in range(w)]
+            assert sum(sizes) == n and min(sizes) >= 0
+            chunk = 8192
+            while chunk > 1 and n < 8 * w * chunk:
+                chunk //= 2
+            assert max(sizes) - min(sizes) <= (chunk if w > 1 else 0)
+            if w > 1 and n >= 8 * w:
+                assert min(sizes) >= 7 * chunk
 
 
 def test_vtkicp_defaults_and_errors(capsys):
