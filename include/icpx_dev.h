@@ -97,6 +97,12 @@ extern "C"
    * measurements.  Sums over all shards are the same to rounding. */
   int icpx_set_shard_order(icpx_ctx* ctx, int order);
 
+  /* Where a query without a winner of a last pass gets its first bound from, in the
+   * one-walk-per-wavefront kernel: 1 (default) = the better of the triangle its cell of a
+   * coarse grid over the target's bounds names and the nearest of the eight around its place
+   * on the triangles' Morton curve; 0 = the curve's alone; 2 = the grid's alone.  Same results. */
+  int icpx_set_seed(icpx_ctx* ctx, int mode);
+
   /* 1 (default): a cloud of a quarter of a million points or more per rank whose mean residual
    * stays beyond the reach of the shortcut's neighbour lists (a noisy scan) goes by the large
    * cloud's policy whatever its size; 0: the policy goes by size alone.  For measurements. */

@@ -299,6 +299,9 @@ struct icpx_ctx
   uint64_t* d_tcodes = nullptr; // sorted Morton codes of the triangles
   uint32_t* d_tcell = nullptr;  // first position per leading tcell_bits bits of a code (k_code_cells)
   int tcell_bits = 0;
+  int32_t* d_seed = nullptr;    // a near triangle per cell of a coarse grid over the bounds (k_seed_flood)
+  int seed_dim = 0;
+  int seed_mode = 1;            // cold seeds: 0 the Morton curve's, 1 the grid's and the curve's, 2 the grid's
   float4* d_tpre = nullptr;     // per-triangle plane bounds
   float* d_cert = nullptr;      // per query: the shortcut's certificate (see local.hpp)
   uint32_t* d_ticket = nullptr; // k_reduce_solve's count of finished blocks (zero between launches)
@@ -636,6 +639,7 @@ static void free_target(icpx_ctx* c)
   dev_free(&c->d_tid);
   dev_free(&c->d_tcodes);
   dev_free(&c->d_tcell);
+  dev_free(&c->d_seed);
   dev_free(&c->d_tpre);
   dev_free(&c->d_fn);
   dev_free(&c->d_fnpos);
@@ -1096,6 +1100,16 @@ extern "C" int icpx_set_query_curve(icpx_ctx* c, int hilbert)
   return ICPX_OK;
 }
 
+extern "C" int icpx_set_seed(icpx_ctx* c, int mode)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  if (mode < 0 || mode > 2)
+    return fail(ICPX_E_INVALID, "seed mode must be 0 (curve), 1 (grid and curve) or 2 (grid), got %d", mode);
+  c->seed_mode = mode;
+  return ICPX_OK;
+}
+
 extern "C" int icpx_set_noisy_policy(icpx_ctx* c, int enable)
 {
   if (!c)
@@ -1312,7 +1326,35 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
     k_code_cells<<<nblk(((int64_t)1 << cbits) + 1, 256), 256, 0, st>>>(c->d_tcodes, nt, cbits, c->d_tcell);
     e = hipGetLastError();
   }
+  // the seed grid: about four cells per triangle, 16^3 to 256^3
+  int sdim = 16;
+  while (sdim < 256 && (int64_t)sdim * sdim * sdim < 4 * nt)
+    sdim *= 2;
+  int32_t* seed_tmp = nullptr;
+  const int64_t scells = (int64_t)sdim * sdim * sdim;
+  if (e == hipSuccess && !rc)
+    rc = dev_alloc(&c->d_seed, scells);
+  if (e == hipSuccess && !rc)
+    rc = dev_alloc(&seed_tmp, scells);
+  if (e == hipSuccess && !rc)
+  {
+    c->seed_dim = sdim;
+    e = hipMemsetAsync(c->d_seed, 0xff, sizeof(int32_t) * scells, st);
+    k_seed_scatter<<<nblk(nt, 256), 256, 0, st>>>(c->d_tpre, nt, c->box, sdim,
+      reinterpret_cast<uint32_t*>(c->d_seed));
+    int32_t *src = c->d_seed, *dst = seed_tmp;
+    for (int stride = sdim / 2; stride >= 1; stride /= 2)
+    {
+      k_seed_flood<<<nblk(scells, 256), 256, 0, st>>>(src, dst, c->d_tpre, c->box, sdim, stride);
+      std::swap(src, dst);
+    }
+    if (src != c->d_seed) // (the last pass wrote the other buffer: that one is kept)
+      std::swap(c->d_seed, seed_tmp);
+    if (e == hipSuccess)
+      e = hipGetLastError();
+  }
   const hipError_t es = hipStreamSynchronize(st); // (the sort's buffers are in use until here)
+  dev_free(&seed_tmp);
   if (e == hipSuccess)
     e = es;
   drop_sort();
@@ -2157,6 +2199,9 @@ static int run_search3(icpx_ctx* c)
   a.tcell = c->d_tcell;
   a.tcell_bits = c->tcell_bits;
   a.box = c->box;
+  a.seed_grid = c->seed_mode ? c->d_seed : nullptr;
+  a.seed_dim = c->seed_dim;
+  a.seed_morton = c->seed_mode == 2 ? 0 : 1;
   a.cand = c->d_cand;
   a.tie_list = c->d_tie_list;
   a.counters = c->d_counters;

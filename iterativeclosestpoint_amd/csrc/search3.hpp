@@ -275,6 +275,11 @@ struct Search3Args
   const uint32_t* tcell;
   int tcell_bits;
   Box3 box;
+  // ... and a triangle near each cell of a coarse grid over the bounds (k_seed_flood; null:
+  // none).  seed_morton: the curve's seed is looked at as well (the better of the two wins).
+  const int32_t* seed_grid;
+  int seed_dim;
+  int seed_morton;
   // contested queries
   int32_t* cand;        // [nq][RING3]
   uint2* tie_list;      // {query, contenders}
@@ -980,6 +985,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   }
 }
 
+// A first bound for a query that has no winner of a last pass to start from, wherever it is:
+// a coarse grid over the target's bounds (dim^3 cells) whose every cell names a triangle
+// (Morton position) with a centroid near the cell's centre.  Cells that hold centroids take
+// one of them (the smallest position); the others are filled by flooding in halving strides
+// (each pass a cell looks at its 26 neighbours at the stride and keeps the nearest centroid
+// it has seen), which finds a near triangle, not always the nearest: good enough for a bound.
+// The query's place on the triangles' Morton curve (the other seed) names a near triangle
+// only when the query is on the surface; a point a few dozen edge lengths off it, as most
+// are at the start of a registration, has curve neighbours as far away again.
+__device__ __forceinline__ int64_t seed_cell_of(float x, float y, float z, const Box3& b, int dim)
+{
+  const float fd = (float)dim;
+  const int ix = min((int)(fminf(fmaxf((x - b.lo[0]) * b.inv[0], 0.f), 1.f) * fd), dim - 1);
+  const int iy = min((int)(fminf(fmaxf((y - b.lo[1]) * b.inv[1], 0.f), 1.f) * fd), dim - 1);
+  const int iz = min((int)(fminf(fmaxf((z - b.lo[2]) * b.inv[2], 0.f), 1.f) * fd), dim - 1);
+  return ((int64_t)iz * dim + iy) * dim + ix;
+}
+
+__global__ void k_seed_scatter(const float4* __restrict__ tpre, int64_t nt, Box3 b, int dim,
+  uint32_t* __restrict__ grid)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nt || tpre[2 * s].w < 0.f)
+    return; // (a degenerate triangle is nobody's closest cell)
+  const float4 c = tpre[2 * s + 1];
+  atomicMin(&grid[seed_cell_of(c.x, c.y, c.z, b, dim)], (uint32_t)s); // (empty cells hold 0xffffffff)
+}
+
+__global__ void k_seed_flood(const int32_t* __restrict__ in, int32_t* __restrict__ out,
+  const float4* __restrict__ tpre, Box3 b, int dim, int stride)
+{
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)dim * dim * dim)
+    return;
+  const int ix = (int)(idx % dim), iy = (int)((idx / dim) % dim), iz = (int)(idx / ((int64_t)dim * dim));
+  const float inv = 1.f / (float)dim;
+  // the cell's centre (an axis the target has no extent along: inv = 0, every cell at lo)
+  const float cx = b.lo[0] + (b.inv[0] > 0.f ? ((float)ix + 0.5f) * inv / b.inv[0] : 0.f);
+  const float cy = b.lo[1] + (b.inv[1] > 0.f ? ((float)iy + 0.5f) * inv / b.inv[1] : 0.f);
+  const float cz = b.lo[2] + (b.inv[2] > 0.f ? ((float)iz + 0.5f) * inv / b.inv[2] : 0.f);
+  int32_t best = in[idx];
+  float bd = INFINITY;
+  if (best >= 0)
+  {
+    const float4 c = tpre[2 * (int64_t)best + 1];
+    bd = (c.x - cx) * (c.x - cx) + (c.y - cy) * (c.y - cy) + (c.z - cz) * (c.z - cz);
+  }
+  for (int dz = -1; dz <= 1; dz++)
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++)
+      {
+        const int jx = ix + dx * stride, jy = iy + dy * stride, jz = iz + dz * stride;
+        if ((dx | dy | dz) == 0 || jx < 0 || jy < 0 || jz < 0 || jx >= dim || jy >= dim || jz >= dim)
+          continue;
+        const int32_t t = in[((int64_t)jz * dim + jy) * dim + jx];
+        if (t < 0 || t == best)
+          continue;
+        const float4 c = tpre[2 * (int64_t)t + 1];
+        const float d = (c.x - cx) * (c.x - cx) + (c.y - cy) * (c.y - cy) + (c.z - cz) * (c.z - cz);
+        if (d < bd || (d == bd && t < best))
+        {
+          bd = d;
+          best = t;
+        }
+      }
+  out[idx] = best;
+}
+
 // lower and upper fp32 bounds of the squared distance from the query to a triangle, from
 // its record {unit normal, plane allowance} {centroid, radius}
 // (RAW: the hardware's square root, within one unit in the last place, which the factors
@@ -1326,7 +1399,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         qbest = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
         stale = qbest > 16.f * rb.w * rb.w;
       }
-      if ((hs < 0 || stale) && a.tcodes)
+      if ((hs < 0 || stale) && a.seed_grid)
+      {
+        // the triangle the query's grid cell names
+        const int32_t gs = a.seed_grid[seed_cell_of(xf, yf, zf, a.box, a.seed_dim)];
+        if (gs >= 0)
+        {
+          const float4 rb = a.tpre[2 * (int64_t)gs + 1];
+          const float vx = xf - rb.x, vy = yf - rb.y, vz = zf - rb.z;
+          const float q2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
+          if (q2 < qbest)
+          {
+            qbest = q2;
+            hs = gs;
+          }
+        }
+      }
+      if ((hs < 0 || stale) && a.tcodes && (a.seed_morton || !a.seed_grid))
       {
         // of the few triangles around the query's place on the Morton curve, the one with
         // the nearest centroid gives the first bound

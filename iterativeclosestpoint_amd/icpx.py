@@ -34,7 +34,7 @@ DEV_SYMBOLS = (
     "icpx_get_timing", "icpx_get_pass_timings", "icpx_set_exhaustive", "icpx_set_leaf_size",
     "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local", "icpx_set_refill",
     "icpx_set_finalize", "icpx_set_lean", "icpx_set_anchor", "icpx_set_shard_order",
-    "icpx_set_certify_min", "icpx_set_wave_blocks", "icpx_set_query_curve", "icpx_set_noisy_policy",
+    "icpx_set_certify_min", "icpx_set_wave_blocks", "icpx_set_query_curve", "icpx_set_noisy_policy", "icpx_set_seed",
 )
 
 
@@ -99,6 +99,7 @@ def load():
     lib.icpx_set_wave_blocks.argtypes = [vp, ci]
     lib.icpx_set_query_curve.argtypes = [vp, ci]
     lib.icpx_set_noisy_policy.argtypes = [vp, ci]
+    lib.icpx_set_seed.argtypes = [vp, ci]
     lib.icpx_run_end.argtypes = [vp, vp, C.POINTER(ci), C.POINTER(dbl), C.POINTER(ci)]
     lib.icpx_last_build_seconds.argtypes = [vp]
     lib.icpx_last_build_seconds.restype = dbl
@@ -330,6 +331,10 @@ class Context:
 
     def set_wave_blocks(self, blocks_per_cu):
         _chk(load().icpx_set_wave_blocks(self._h, int(blocks_per_cu)))
+
+    def set_seed(self, mode):
+        """Cold seeds of the wavefront walk: 0 Morton curve, 1 grid and curve (default), 2 grid."""
+        _chk(load().icpx_set_seed(self._h, int(mode)))
 
     def set_noisy_policy(self, enable):
         _chk(load().icpx_set_noisy_policy(self._h, int(enable)))

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--wave-blocks", default="19")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--curve", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     c = {"c3": synth.config_c3, "c4": synth.config_c4}[a.workload]()
     metric = c["metric"]
@@ -27,6 +28,7 @@ def main():
     ctx.set_source(c["source_xyz"], c["source_normals"])
     ctx.set_shard_order(a.order)
     ctx.set_query_curve(a.curve)
+    ctx.set_seed(a.seed)
     for world in [int(v) for v in a.worlds.split(",")]:
         for rank in sorted({0, world // 2}):
             ctx.set_shard(rank, world)
