@@ -629,6 +629,15 @@ def test_full_size_c3(icpx, synth, oracle):
     p.metric, p.max_iterations, p.max_landmarks, p.max_distance = 2, 30, n, 10.0
     T, it, mean, st = ctx.run(p)
     assert it == 30 and np.abs(T @ c["truth"] - np.eye(4)).max() < 1e-6 and mean < 1e-6
+    # the benchmark's registration (50 iterations) with lean passes off and on: the same bits
+    p.max_iterations = 50
+    res = {}
+    for mode in (0, 1):
+        ctx.set_lean(mode)
+        before = ctx.debug_stats()["lean_passes"]
+        res[mode] = ctx.run(p) + (ctx.debug_stats()["lean_passes"] - before,)
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1:4] == res[1][1:4]
+    assert res[0][4] == 0 and res[1][4] >= 35, (res[0][4], res[1][4])
 
 
 def test_large_target_c4_sample(icpx, synth, oracle):
@@ -738,6 +747,78 @@ def test_full_size_c4(icpx, synth, oracle):
     d = np.linalg.norm(rows["origin"].astype(np.float64) - rows["closest"].astype(np.float64), axis=1)
     assert np.abs(d - rows["dist"]).max() <= 1e-6
     assert abs(d.mean() - mean) <= 1e-6            # the loop's last mean distance is one solve old
+    del rows, d
+    # (5) The whole loop against the oracle on this geometry: MaximumNumberOfLandmarks = 1e6, so
+    # the filter's stride rule keeps every 16th of the 16M points
+    # (ICP/vtkPolyDataCorrespondenceFilter.cxx:473-477), 50 point-to-plane iterations
+    # (ICP/vtkICP.cxx:189-246).  The golden 4x4 after every iteration comes from the CPU oracle
+    # (tools/make_c4_loop_golden.py); the north star's gate is 1e-6 relative on the final one.
+    loop = np.load(os.path.join(os.path.dirname(__file__), "golden", "c4_loop_1m_landmarks.npz"))
+    assert int(loop["landmarks"]) == 1_000_000 and int(loop["step"]) == 16 and loop["T"].shape == (50, 4, 4)
+    p.max_landmarks = int(loop["landmarks"])
+    gaps = {}
+    for k in (1, 2, 3, 5, 10, 20, 50):
+        p.max_iterations = k
+        Tk, it, mean_k, st = ctx.run(p)
+        assert it == k
+        gaps[k] = rel_err(Tk, loop["T"][k - 1])
+        # (the library's mean distance is that of the last pass searched: the oracle's pass k)
+        assert abs(mean_k - float(loop["mean"][k - 1])) <= 1e-9, (k, mean_k, float(loop["mean"][k - 1]))
+    print("50-iteration loop, 1e6 landmarks on the 10M-triangle target, relative gap to the "
+          "oracle's 4x4 after k iterations:", {k: "%.2e" % v for k, v in gaps.items()})
+    # (the first solve sees the same rows: rounding alone.  From the second on, the two
+    # transforms differ in their last bits, a few of a million noisy points lie within that of
+    # an edge between two triangles and take the other one's normal: 1e-9 of the sums)
+    assert gaps[1] <= 1e-12 and max(gaps[k] for k in (2, 3)) <= 1e-8, gaps
+    assert max(gaps.values()) <= 1e-6, gaps
+    assert np.all(loop["n"] == 1_000_000)
+
+
+def test_full_size_c5(icpx, synth, oracle):
+    """The partial-overlap, outlier-heavy pair at the benchmark's size (0.59M triangles, 0.84M
+    points of which a quarter end up within the threshold): rows at the start pose and at the
+    registered pose against the oracle (a 6000-point sample each, accepted and rejected alike),
+    properties of every accepted row, and the same registration with lean passes off and on and
+    with the noisy cloud's policy off and on: identical bits."""
+    c = synth.config_c5(nu=1000, nv=500, npts=1_200_000)
+    n = len(c["source_xyz"])
+    ctx = icpx.Context(0)
+    ctx.set_target(c["target_xyz"], c["target_tri"])
+    ctx.set_source(c["source_xyz"])
+    mesh = oracle.Mesh(c["target_xyz"], c["target_tri"])
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = c["metric"], 50, n, c["max_dist"]
+    res = {}
+    for name, lean, noisy in (("default", 1, 1), ("no lean passes", 0, 1), ("policy by size alone", 1, 0)):
+        ctx.set_lean(lean)
+        ctx.set_noisy_policy(noisy)
+        res[name] = ctx.run(p)
+    ctx.set_lean(1)
+    ctx.set_noisy_policy(1)
+    T, it, mean, st = res["default"]
+    assert it == 50 and st == icpx.RUN_MAX_ITERATIONS
+    for name, r in res.items():
+        assert np.array_equal(r[0], T) and r[1:] == res["default"][1:], name
+    pick = (np.arange(6_000) * 139 + 7).astype(np.int64)
+    for pose in (np.eye(4), T):
+        rows = ctx.correspond(pose, step=1, max_dist=c["max_dist"])
+        assert 0.15 * n < len(rows["cell"]) < 0.5 * n          # the threshold drops most
+        ref = mesh.correspond(c["source_xyz"][pick], T=pose, step=1, max_dist=c["max_dist"], grid=True)
+        at = np.searchsorted(rows["src_index"], pick[ref["src_index"]])
+        assert np.array_equal(rows["src_index"][at], pick[ref["src_index"]])
+        # (the sample's accepted rows are exactly those of the library's that fall in the sample)
+        assert np.isin(rows["src_index"], pick).sum() == len(ref["cell"])
+        for key in ("cell", "dist", "closest"):
+            assert np.array_equal(rows[key][at], ref[key]), key
+        assert np.abs(rows["normal"][at] - ref["normal"]).max() <= 1e-6
+        assert rows["dist"].max() < c["max_dist"]
+        d = np.linalg.norm(rows["origin"].astype(np.float64) - rows["closest"].astype(np.float64), axis=1)
+        assert np.abs(d - rows["dist"]).max() <= 1e-6
+    # too small a threshold: nothing is accepted and the run stops for want of rows (the
+    # reference has no such handling: ICP/icp/plane2plane.cxx:41-42 takes the mean of nothing)
+    p.max_distance = 1e-9
+    Tn, itn, _, stn = ctx.run(p)
+    assert stn == icpx.RUN_TOO_FEW and itn == 0 and np.array_equal(Tn, np.eye(4))
 
 
 def test_device_loop_with_rccl_collective(icpx, synth, small):
