@@ -87,7 +87,9 @@ extern "C"
    * the winding of its lowest-numbered cell (cells that run along a shared edge in the same
    * direction as their neighbour are reversed), which is what VTK's walk from the lowest
    * unvisited cell yields for orientable pieces; edges shared by more than two cells are not
-   * walked across.
+   * walked across.  A piece that cannot be wound consistently (a Moebius band) keeps a seam
+   * of cells that disagree with their neighbours, as it does in VTK; where that seam runs is
+   * not defined (icpx_dev.h: icpx_debug_dump reports that such a piece was met).
    * normals_out: 3 * nv floats.  The context only supplies the device and the stream. */
   int icpx_point_normals(icpx_ctx* ctx, const float* xyz, int64_t nv, const int32_t* tri,
     int64_t nt, float* normals_out);
@@ -149,7 +151,8 @@ extern "C"
    * ends).  The meshes are the context's (icpx_set_target / icpx_set_source, which do
    * allocate, come first); the ICPX_NSUMS sums are left in the caller's device buffer
    * sums_device, stream-ordered; arguments otherwise as icpx_accumulate.  Same sums, bit
-   * for bit, as icpx_accumulate gives for the same arguments.
+   * for bit, as icpx_accumulate gives for the same arguments with the default kernels (the
+   * development switches of icpx_dev.h that pick other search kernels do not reach here).
    * Limits: at most ICPX_STATIC_MAX_QUERIES kept points in this context's shard (in the whole
    * job when the context is one of several shards: all of them are ordered to cut the shard
    * out; more is ICPX_E_INVALID: use icpx_accumulate or a larger step), and the search tree of that size

@@ -141,7 +141,8 @@ extern "C"
    * the wavefront walk served and how many the pooled lanes, cells the last
    * icpx_point_normals reversed for consistent winding, passes that sent the light
    * kernel's list straight to the tree kernels, lean passes enqueued, lean passes that
-   * failed and were repeated in full} (13 x int64); 5: the shortcut's
+   * failed and were repeated in full, whether the last icpx_point_normals met a piece that
+   * cannot be wound consistently} (14 x int64); 5: the shortcut's
    * certificates (float per query of
    * this shard: how far the query may still move before its winner is looked at again,
    * 0 = none, negative = how far before something may come within the distance threshold;

@@ -416,6 +416,7 @@ struct icpx_ctx
   int exhaustive = 0;
   double build_seconds = 0.0;
   int64_t last_flips = 0; // cells the last icpx_point_normals reversed for consistent winding
+  bool last_unorientable = false; // ... and whether it met a piece that cannot be wound consistently
 
   // source
   int64_t np = 0;
@@ -945,10 +946,11 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
   }
   else if (what == 4)
   {
-    int64_t v[13] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
+    int64_t v[14] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
       c->nbr_total, c->certify_passes, c->split_passes, c->split_wave, c->split_pool,
-      c->last_flips, c->direct_passes, c->lean_passes, c->lean_failures };
-    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 13));
+      c->last_flips, c->direct_passes, c->lean_passes, c->lean_failures,
+      c->last_unorientable ? 1 : 0 };
+    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 14));
     return ICPX_OK;
   }
   else if (what == 3 && c->d_ovf_best)
@@ -1508,14 +1510,15 @@ extern "C" int icpx_point_normals(icpx_ctx* c, const float* xyz, int64_t nv, con
   }
   // ConsistencyOn: cells wound against their piece's lowest cell are reversed first
   c->last_flips = 0;
+  c->last_unorientable = false;
   if (e == hipSuccess)
   {
     // (fn64 is not needed yet: its memory holds the neighbour table and the labels meanwhile)
     int32_t* nbr = reinterpret_cast<int32_t*>(fn64);          // 3 nt int32
     uint32_t* lab = reinterpret_cast<uint32_t*>(fn64) + 3 * nt; // nt uint32 (fn64 has 6 nt words)
-    uint32_t* flags = cursor;                                   // [0] inconsistent edges, [1] changed, [2] flipped
-    uint32_t h_flags[3] = { 0, 0, 0 };
-    e = hipMemsetAsync(flags, 0, 3 * sizeof(uint32_t), st);
+    uint32_t* flags = cursor; // [0] inconsistent edges, [1] changed, [2] flipped, [3] a piece that cannot be wound consistently
+    uint32_t h_flags[4] = { 0, 0, 0, 0 };
+    e = hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), st);
     if (e == hipSuccess)
     {
       k_edge_neighbours<<<nblk(3 * nt, 256), 256, 0, st>>>(d_tri, voff, vcell, nt, nbr, flags);
@@ -1526,13 +1529,17 @@ extern "C" int icpx_point_normals(icpx_ctx* c, const float* xyz, int64_t nv, con
     if (e == hipSuccess && h_flags[0] != 0)
     {
       k_orient_init<<<nblk(nt, 256), 256, 0, st>>>(nt, lab);
-      // the smallest cell id of a piece reaches its far end after as many sweeps as the
-      // piece is cells across; look every few dozen sweeps whether anything still moves
+      // the smallest cell id of a piece reaches every cell of it after a number of sweeps that
+      // grows with the logarithm of the piece's length (the sweeps also follow the labels'
+      // own references); look every few dozen sweeps whether anything still moves
       for (int64_t round = 0; e == hipSuccess && round <= nt / 32 + 1; round++)
       {
         e = hipMemsetAsync(flags + 1, 0, sizeof(uint32_t), st);
         for (int k = 0; k < 32 && e == hipSuccess; k++)
-          k_orient_sweep<<<nblk(nt, 256), 256, 0, st>>>(nbr, nt, lab, flags + 1);
+        {
+          k_orient_sweep<<<nblk(nt, 256), 256, 0, st>>>(nbr, nt, lab, flags + 1, flags + 3);
+          e = hipGetLastError();
+        }
         if (e == hipSuccess)
           e = hipMemcpyAsync(h_flags + 1, flags + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess)
@@ -1543,11 +1550,12 @@ extern "C" int icpx_point_normals(icpx_ctx* c, const float* xyz, int64_t nv, con
       if (e == hipSuccess)
       {
         k_orient_apply<<<nblk(nt, 256), 256, 0, st>>>(lab, nt, d_tri, flags + 2);
-        e = hipMemcpyAsync(h_flags + 2, flags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        e = hipMemcpyAsync(h_flags + 2, flags + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
       }
       if (e == hipSuccess)
         e = hipStreamSynchronize(st);
       c->last_flips = h_flags[2];
+      c->last_unorientable = h_flags[3] != 0;
     }
   }
   if (e == hipSuccess)
@@ -2843,17 +2851,29 @@ extern "C" int icpx_accumulate_static(icpx_ctx* c, int metric, const double T[16
       (long long)nk, (long long)STATIC_MAX_QUERIES);
   if (rs_scratch_words(curve ? nk : nq) > (int64_t)ST_SORT_WORDS)
     return fail(ICPX_E_INVALID, "icpx_accumulate_static: sort scratch too small");
-  if (c->device >= ST_MAX_DEVICES || !g_scratch_ptr[c->device])
+  unsigned char* base = nullptr;
+  if (c->device < ST_MAX_DEVICES)
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    base = g_scratch_ptr[c->device];
+  }
+  if (!base)
     return fail(ICPX_E_INVALID, "icpx_accumulate_static: no scratch address for device %d",
       c->device);
-  // the search tree of this size class is built (allocated) by the first ordinary pass
-  const int G = nq <= 4096 ? 64 : 8;
+  // The search tree of this size class is built (allocated) by the first ordinary pass: the
+  // one icpx_accumulate picks for this many queries, which goes by the development switches
+  // (icpx_set_group_width, icpx_set_exhaustive) when they are set.  This entry point runs the
+  // wavefront-per-query or the eight-lanes-per-query search over its heap tree, nothing else.
+  int G = nq <= 4096 ? 64 : 8;
+  if (c->group_width == 8 || c->group_width == 64)
+    G = c->group_width;
   const int slot = G == 64 ? 4 : 1;
   const Heap& h = c->heaps[slot];
   if (nq > 0 && !h.built)
     return fail(ICPX_E_INVALID,
-      "icpx_accumulate_static: the %d-ary search tree is not built yet; one icpx_accumulate "
-      "call with the same step builds it (that call allocates)", G);
+      "icpx_accumulate_static: the %d-ary search tree is not built yet; one icpx_accumulate call "
+      "with the same step and the default kernels (icpx_set_group_width 0 or %d, "
+      "icpx_set_exhaustive 0) builds it (that call allocates)", G, G);
   HIPCHK(hipSetDevice(c->device));
   c->run_active = false;
   hipStream_t st = c->stream;
@@ -2862,7 +2882,6 @@ extern "C" int icpx_accumulate_static(icpx_ctx* c, int metric, const double T[16
     HIPCHK(hipMemsetAsync(sums_device, 0, sizeof(double) * ICPX_NSUMS, st));
     return ICPX_OK;
   }
-  unsigned char* base = g_scratch_ptr[c->device];
   uint64_t* ka = reinterpret_cast<uint64_t*>(base + ST_OFF_KA);
   uint64_t* kb = reinterpret_cast<uint64_t*>(base + ST_OFF_KB);
   uint32_t* va = reinterpret_cast<uint32_t*>(base + ST_OFF_VA);

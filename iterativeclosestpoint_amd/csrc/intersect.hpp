@@ -98,6 +98,10 @@ __device__ __forceinline__ bool slab(const d3& p1, const d3& d, float lox, float
   const double lo[3] = { (double)lox - m, (double)loy - m, (double)loz - m };
   const double hi[3] = { (double)hix + m, (double)hiy + m, (double)hiz + m };
   const double o[3] = { p1.x, p1.y, p1.z }, dd[3] = { d.x, d.y, d.z };
+  // (the padding nodes of a tree that is not a power of two hold the empty box, lo = +inf,
+  // hi = -inf: the quotients below would swap into (-inf, +inf) and let a segment in)
+  if (lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2])
+    return false;
 #pragma unroll
   for (int a = 0; a < 3; a++)
   {
@@ -122,7 +126,7 @@ __device__ __forceinline__ bool slab(const d3& p1, const d3& d, float lox, float
     }
   }
   tnear = t0;
-  return t0 <= t1; // (an empty box has lo = +inf, hi = -inf: never)
+  return t0 <= t1;
 }
 
 template <int L>

@@ -156,15 +156,22 @@ __global__ void k_orient_init(int64_t nt, uint32_t* __restrict__ lab)
 }
 
 // One sweep: every cell takes the smallest label among its neighbours', with the parity the
-// relation across the edge gives.  Labels only ever decrease, so sweeps may overlap freely.
+// relation across the edge gives, and then looks where the cell its label names has got to
+// meanwhile (that cell's own label, the two parities combined): labels travel along chains of
+// such references as well as from neighbour to neighbour, so a long thin piece settles in a
+// number of sweeps that grows with the logarithm of its length, not with the length.  Labels
+// only ever decrease, so sweeps may overlap freely.  A neighbour that carries the cell's own
+// label with the other parity belongs to a piece that cannot be wound consistently (a Moebius
+// band): *conflict is raised; which of its cells end up reversed then depends on the order in
+// which the sweeps happened to run.
 __global__ void k_orient_sweep(const int32_t* __restrict__ nbr, int64_t nt,
-  uint32_t* __restrict__ lab, uint32_t* __restrict__ changed)
+  uint32_t* __restrict__ lab, uint32_t* __restrict__ changed, uint32_t* __restrict__ conflict)
 {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nt)
     return;
   uint32_t best = lab[c];
-  bool ch = false;
+  bool ch = false, clash = false;
 #pragma unroll
   for (int e = 0; e < 3; e++)
   {
@@ -178,12 +185,23 @@ __global__ void k_orient_sweep(const int32_t* __restrict__ nbr, int64_t nt,
       best = cand;
       ch = true;
     }
+    else if ((cand >> 1) == (best >> 1) && cand != best)
+      clash = true;
+  }
+  // (the label's cell relative to ITS label, and this cell relative to that one)
+  const uint32_t up = *reinterpret_cast<volatile uint32_t*>(&lab[best >> 1]);
+  if ((up >> 1) < (best >> 1))
+  {
+    best = (up & ~1u) | ((up ^ best) & 1u);
+    ch = true;
   }
   if (ch)
   {
     lab[c] = best;
     *changed = 1u;
   }
+  if (clash)
+    *conflict = 1u;
 }
 
 // vtkPolyData::ReverseCell on the cells found flipped: (p0, p1, p2) -> (p2, p1, p0).

@@ -193,13 +193,14 @@ class Context:
 
     def debug_stats(self):
         """{shortcut passes, tree-only passes, neighbour-list builds, list radius}."""
-        v = np.zeros(13, np.int64)
-        _chk(load().icpx_debug_dump(self._h, 4, _p(v), 13))
+        v = np.zeros(14, np.int64)
+        _chk(load().icpx_debug_dump(self._h, 4, _p(v), 14))
         return dict(local_passes=int(v[0]), tree_passes=int(v[1]), nbr_builds=int(v[2]),
                     nbr_eps=float(v[3]) * 1e-9, nbr_total=int(v[4]), certify_passes=int(v[5]),
                     split_passes=int(v[6]), split_wave=int(v[7]), split_pool=int(v[8]),
                     winding_flips=int(v[9]), direct_passes=int(v[10]),
-                    lean_passes=int(v[11]), lean_failures=int(v[12]))
+                    lean_passes=int(v[11]), lean_failures=int(v[12]),
+                    unorientable=bool(v[13]))
 
     def debug_counters(self):
         """Counters of the last lane-per-query pass: {ties, overflows, pool position, fallbacks}."""

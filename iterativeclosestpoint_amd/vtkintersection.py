@@ -3,7 +3,11 @@
 `vtkImplicitPolyDataIntersection` here has the methods and defaults of the reference's class
 (ICP/vtkImplicitPolyDataIntersection.h:31-150, ICP/vtkImplicitPolyDataIntersection.cxx:29-337):
 SetInput(polydata), IntersectWithLine(p1, p2) and the NoValue / NoGradient /
-NoClosestPoint / Tolerance members.  The search is `icpx_intersect_lines`; `IntersectWithLines`
+NoClosestPoint / Tolerance members.  IntersectWithLine returns the first three for a segment
+that misses, whatever the caller has set them to; Tolerance is kept for the interface's sake:
+the library's intersection test runs at the reference's default of 1e-12 (.cxx:148) and a
+changed value is not passed on.  Among several cells hit at the same parameter the library
+takes the smallest cell id, where vtkCellLocator's order of buckets decides in the reference.  The search is `icpx_intersect_lines`; `IntersectWithLines`
 (plural) takes many segments in one call, which is how a GPU wants them.
 """
 import sys
@@ -68,5 +72,10 @@ class vtkImplicitPolyDataIntersection:
         if r is None:
             return 0, self.NoValue, self.NoClosestPoint.copy(), self.NoGradient.copy(), \
                 NUMBER_OF_ATTRIBUTE_TYPES
+        if int(r["hit"][0]) == 0:
+            # no intersection: the instance's own members, as the reference returns them
+            # (.cxx:114-124); a caller may have changed them
+            return 0, self.NoValue, np.array(self.NoClosestPoint, np.float64), \
+                np.array(self.NoGradient, np.float64), NUMBER_OF_ATTRIBUTE_TYPES
         kind = {0: CELL, 1: EDGE, 2: VERTEX}.get(int(r["kind"][0]), NUMBER_OF_ATTRIBUTE_TYPES)
         return int(r["hit"][0]), float(r["ret"][0]), r["closest"][0], r["normal"][0], kind

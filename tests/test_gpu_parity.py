@@ -1269,6 +1269,43 @@ def test_point_normals_with_inconsistent_winding(icpx, synth, oracle):
     assert np.abs(oracle.point_normals(xyz2, bad, consistency=False) - inv).max() > 0.5
 
 
+def test_point_normals_on_a_long_strip_and_a_moebius_band(icpx, synth):
+    """The consistency pass on a piece that is 200 000 cells long and one cell wide (labels
+    must not need a sweep per cell to cross it), and on a band with a half twist, which
+    cannot be wound consistently: that is reported."""
+    n = 100_000
+    i = np.arange(n + 1, dtype=np.float32)
+    xyz = np.zeros((2 * (n + 1), 3), np.float32)
+    xyz[0::2, 0], xyz[1::2, 0], xyz[1::2, 1] = i, i, 1.0
+    k = np.arange(n, dtype=np.int32)
+    tri = np.empty((2 * n, 3), np.int32)
+    tri[0::2] = np.stack([2 * k, 2 * k + 2, 2 * k + 1], -1)
+    tri[1::2] = np.stack([2 * k + 1, 2 * k + 2, 2 * k + 3], -1)
+    flip = synth.u01(7, 3, len(tri)) < 0.4
+    flip[0] = False
+    bad = tri.copy()
+    bad[flip] = bad[flip][:, [1, 0, 2]]
+    ctx = icpx.Context(0)
+    got = ctx.point_normals(xyz, bad)
+    st = ctx.debug_stats()
+    assert st["winding_flips"] == int(flip.sum()) and not st["unorientable"]
+    assert np.array_equal(got, np.tile(np.array([0, 0, 1], np.float32), (len(xyz), 1)))
+    # a band with a half twist: 64 quads, the last joined to the first upside down
+    m = 64
+    t = 2 * np.pi * np.arange(m) / m
+    mid = np.stack([np.cos(t), np.sin(t), np.zeros(m)], -1)
+    off = 0.3 * np.stack([np.cos(t / 2) * np.cos(t), np.cos(t / 2) * np.sin(t), np.sin(t / 2)], -1)
+    band = np.empty((2 * m, 3), np.float32)
+    band[0::2], band[1::2] = mid - off, mid + off
+    q = np.arange(m, dtype=np.int32)
+    a, b = 2 * q, 2 * q + 1
+    c, d = (2 * (q + 1)) % (2 * m), (2 * (q + 1) + 1) % (2 * m)
+    c[-1], d[-1] = 1, 0                                    # the twist: rows swapped at the seam
+    btri = np.concatenate([np.stack([a, c, b], -1), np.stack([b, c, d], -1)]).astype(np.int32)
+    ctx.point_normals(band, btri)
+    assert ctx.debug_stats()["unorientable"]
+
+
 def test_registration_demo_from_a_file(icpx, synth, tmp_path, capsys):
     """The headless registration demo end to end: a PLY file written here, read by the reader
     factory, perturbed as the reference's demo does and registered back with every metric."""
