@@ -1912,9 +1912,9 @@ static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, uns
     launch_ev(c, false, k_search3w<L, false>, wgrid, 64, st, a);
   else
     launch_ev(c, false, k_search3p<L>, pgrid, 256, st, a);
-  unsigned rgrid = grid / 8 + 1;
-  if (rgrid > 2048)
-    rgrid = 2048;
+  unsigned rgrid = grid / 8 + 1; // (a block of four wavefronts weighs the sets of 2048 queries)
+  if (rgrid > 8192)
+    rgrid = 8192;
   // (overflows are rare: a bounded number of blocks takes them in turns)
   launch_ev(c, true, k_contested<L>, rgrid + std::min(grid, 256u), 256, st, a, rgrid);
 }

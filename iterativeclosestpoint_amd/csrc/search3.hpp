@@ -348,6 +348,7 @@ constexpr int CERTIFY_SEGS = 32;
 // marked queries among a wavefront's 2048 up to which k_contested deals them out to groups
 // of eight lanes (beyond: every lane weighs its own)
 constexpr uint32_t SPARSE_SETS = 16;
+constexpr int SETS_HALVES = 16; // 32-bit words of the set mask a wavefront of k_contested takes at a time
 constexpr int CERTIFY_SEG_STRIDE = 64;
 
 // fp32 lower bound of the squared distance to a box; never above the true value
@@ -1752,19 +1753,25 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
   // (the list's length and the wavefront's first mask words are read side by side, before
   // the transform: in most passes of a clean cloud most wavefronts find nothing and leave
   // after this one round of reads)
+  // A wavefront takes SETS_HALVES half words of the mask at a time (its first lanes one each):
+  // 512 consecutive queries.  (It was 64 half words, 2048 queries: a cloud of a million points
+  // then kept 500 wavefronts busy on a chip that holds 4000, each working through its marked
+  // sets one after the other, two or three dependent reads apiece: 98 us a pass for 0.84 M
+  // points of which a third stand on pairs, 71 us for 2 M noisy ones.)
   const int64_t halves = (a.nq + 31) / 32;
   const uint32_t* const half = reinterpret_cast<const uint32_t*>(a.setmask);
   const int lane = threadIdx.x & 63;
-  const int64_t hfirst = (int64_t)block * 256 + (threadIdx.x & ~63);
+  const int64_t hfirst = ((int64_t)block * 4 + (threadIdx.x >> 6)) * SETS_HALVES;
+  const int64_t hstride = (int64_t)nblocks * 4 * SETS_HALVES;
   const uint32_t total = a.counters[0];
-  const uint32_t bits_first = (a.setmask && hfirst + lane < halves) ? half[hfirst + lane] : 0u;
-  if (block * 32u >= total && hfirst + (int64_t)nblocks * 256 >= halves &&
-    __ballot(bits_first != 0u) == 0ull)
+  const uint32_t bits_first =
+    (a.setmask && lane < SETS_HALVES && hfirst + lane < halves) ? half[hfirst + lane] : 0u;
+  if (block * 32u >= total && hfirst + hstride >= halves && __ballot(bits_first != 0u) == 0ull)
     return;
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
-  __shared__ uint16_t setq[4][2048];
+  __shared__ uint16_t setq[4][SETS_HALVES * 32];
   const int j = threadIdx.x & 7;
   const uint32_t ngroups = nblocks * 32u;
   for (uint32_t r = block * 32u + (threadIdx.x >> 3); r < total; r += ngroups)
@@ -1791,17 +1798,17 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
       a.hint[q] = s;
   }
   // the queries that stand on a set certificate (one bit each in setmask): a wavefront takes
-  // 64 half words, 2048 consecutive queries.  Where many of them are marked (a tenth of a
+  // SETS_HALVES half words, 512 consecutive queries.  Where many of them are marked (a tenth of a
   // noisy cloud stands on sets) every lane weighs the members of its own 32 queries' sets
   // one after the other (cand[], -1 ends a set of fewer than RING3); where few are (a
   // thousand of a million), they are dealt out to groups of eight lanes, one member per
   // lane, so that a pass is one exact evaluation long instead of several in a row.
   if (!a.setmask)
     return;
-  for (int64_t h0 = hfirst; h0 < halves; h0 += (int64_t)nblocks * 256)
+  for (int64_t h0 = hfirst; h0 < halves; h0 += hstride)
   {
     const int64_t h = h0 + lane;
-    uint32_t bits = h0 == hfirst ? bits_first : (h < halves ? half[h] : 0u);
+    uint32_t bits = h0 == hfirst ? bits_first : ((lane < SETS_HALVES && h < halves) ? half[h] : 0u);
     const uint32_t mine = (uint32_t)__popc(bits);
     const uint32_t incl = wave_incl_scan(mine, lane);
     const uint32_t marked = (uint32_t)__shfl((int)incl, 63, 64);
