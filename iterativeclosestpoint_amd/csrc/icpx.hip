@@ -303,7 +303,6 @@ struct icpx_ctx
   int seed_dim = 0;
   int seed_mode = 1;            // cold seeds: 0 the Morton curve's, 1 the grid's and the curve's, 2 the grid's
   float4* d_tpre = nullptr;     // per-triangle plane bounds
-  float4* d_tpk = nullptr;      // ... once more by component, per leaf of four triangles (k_tri_pack4)
   float* d_cert = nullptr;      // per query: the shortcut's certificate (see local.hpp)
   uint32_t* d_ticket = nullptr; // k_reduce_solve's count of finished blocks (zero between launches)
   float *d_fn = nullptr, *d_en = nullptr, *d_vn = nullptr;
@@ -643,7 +642,6 @@ static void free_target(icpx_ctx* c)
   dev_free(&c->d_tcell);
   dev_free(&c->d_seed);
   dev_free(&c->d_tpre);
-  dev_free(&c->d_tpk);
   dev_free(&c->d_fn);
   dev_free(&c->d_fnpos);
   dev_free(&c->d_fn64);
@@ -1313,13 +1311,6 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
   k_tri_bounds<<<nblk(nt + TPRE_PAD, 256), 256, 0, st>>>(
     c->d_tverts, c->d_tid, nt, nt + TPRE_PAD, c->d_tpre);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess)
-    rc = dev_alloc(&c->d_tpk, 8 * ((nt + 3) / 4));
-  if (e == hipSuccess && !rc)
-  {
-    k_tri_pack4<<<nblk((nt + 3) / 4, 256), 256, 0, st>>>(c->d_tpre, (nt + 3) / 4, c->d_tpk);
-    e = hipGetLastError();
-  }
   if (e == hipSuccess)
     rc = dev_alloc(&c->d_tcodes, nt);
   if (e == hipSuccess && !rc)
@@ -2213,7 +2204,6 @@ static int run_search3(icpx_ctx* c)
   a.tid = c->d_tid;
   a.tpre = c->d_tpre;
   a.lpre = b.lpre;
-  a.tpk = c->d_tpk;
   a.nt = c->nt;
   a.hint = c->d_hint;
   a.use_hint = c->hint_valid ? 1 : 0;

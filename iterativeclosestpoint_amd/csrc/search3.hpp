@@ -250,33 +250,6 @@ __global__ void k_leaf_bounds(const float* __restrict__ tverts, const int32_t* _
   lpre[2 * i + 1] = make_float4(cx, cy, cz, __double2float_ru(sqrt(r2) * (1.0 + 1e-12)));
 }
 
-// The triangle records of a leaf of FOUR triangles once more, component by component: eight
-// float4 per leaf, {nx of the four}, {ny}, {nz}, {allowance}, {cx}, {cy}, {cz}, {R}: the
-// wavefront walk holds every triangle of an entered leaf against every lane's bound, and with
-// the same component of two triangles side by side in a register pair those tests go through
-// the packed fp32 instructions (v_pk_fma_f32 and friends) two triangles at a time.
-__global__ void k_tri_pack4(const float4* __restrict__ tpre, int64_t nleaf, float4* __restrict__ pk)
-{
-  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= nleaf)
-    return;
-  float4 a[4], b[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++)
-  {
-    a[t] = tpre[2 * (4 * l + t)]; // (the records are padded past the last triangle)
-    b[t] = tpre[2 * (4 * l + t) + 1];
-  }
-  pk[8 * l + 0] = make_float4(a[0].x, a[1].x, a[2].x, a[3].x);
-  pk[8 * l + 1] = make_float4(a[0].y, a[1].y, a[2].y, a[3].y);
-  pk[8 * l + 2] = make_float4(a[0].z, a[1].z, a[2].z, a[3].z);
-  pk[8 * l + 3] = make_float4(a[0].w, a[1].w, a[2].w, a[3].w);
-  pk[8 * l + 4] = make_float4(b[0].x, b[1].x, b[2].x, b[3].x);
-  pk[8 * l + 5] = make_float4(b[0].y, b[1].y, b[2].y, b[3].y);
-  pk[8 * l + 6] = make_float4(b[0].z, b[1].z, b[2].z, b[3].z);
-  pk[8 * l + 7] = make_float4(b[0].w, b[1].w, b[2].w, b[3].w);
-}
-
 struct Search3Args
 {
   const float* qpos;
@@ -291,7 +264,6 @@ struct Search3Args
   const int32_t* tid;
   const float4* tpre; // per-triangle bounds records (k_tri_bounds), used by k_search3w
   const float4* lpre; // per-leaf bounds records of this tree (k_leaf_bounds), used by k_search3w
-  const float4* tpk;  // the triangle records by component, per leaf of four (k_tri_pack4), or null
   int64_t nt;
   int32_t* hint;
   int use_hint;
@@ -1125,28 +1097,6 @@ __device__ __forceinline__ float tri_lb_rec(float nx, float ny, float nz, float 
   return __builtin_fmaf(ld, ld, pd_lo * pd_lo) * 0.999999f;
 }
 
-// tri_lb_rec for two triangles at once: the same bound with one change: where tri_lb_rec takes
-// the sum of the magnitudes of v's components (for two rounding allowances), this one is given
-// an upper bound of it, `l1b`, that holds for every triangle of the leaf (from the query's
-// offset from the leaf's centre and the leaf's radius), so that the allowances are worked out
-// once per leaf.  A larger sum only lowers the bound.  mb = 6.1e-7 l1b + 4 eabs and
-// wb = -4.00001 eabs l1b come from the caller.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f tri_lb_rec2(v2f nx, v2f ny, v2f nz, v2f allow, v2f R, v2f vx, v2f vy,
-  v2f vz, v2f q2, float mb, float wb, float eabs)
-{
-  const v2f m = allow + mb;
-  const v2f pd = __builtin_elementwise_abs(
-    __builtin_elementwise_fma(nz, vz, __builtin_elementwise_fma(ny, vy, nx * vx)));
-  const v2f zero = { 0.f, 0.f };
-  const v2f pd_lo = __builtin_elementwise_max(pd - m, zero), pd_hi = pd + m;
-  const v2f w = __builtin_elementwise_fma(q2, (v2f){ 0.999998f, 0.999998f }, (v2f){ wb, wb });
-  const v2f in2 = __builtin_elementwise_max(__builtin_elementwise_fma(-pd_hi, pd_hi, w), zero);
-  const v2f rt = { __builtin_amdgcn_sqrtf(in2.x), __builtin_amdgcn_sqrtf(in2.y) };
-  const v2f ld = __builtin_elementwise_max(rt * 0.9999995f - (R + 3.f * eabs), zero);
-  return __builtin_elementwise_fma(ld, ld, pd_lo * pd_lo) * 0.999999f;
-}
-
 // The search with one walk per wavefront.  Queries are in Morton order, so the 64 of a
 // wavefront lie within a few triangle widths of each other and their walks visit nearly
 // the same boxes; here the wavefront walks the tree ONCE for all of them.  The node, the
@@ -1230,7 +1180,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
   cfloat4* nodes4 = (cfloat4*)(uintptr_t)a.nodes;
   cfloat4* tpre4 = (cfloat4*)(uintptr_t)a.tpre;
   cfloat4* lpre4 = (cfloat4*)(uintptr_t)a.lpre;
-  cfloat4* tpk4 = (cfloat4*)(uintptr_t)a.tpk;
 #ifdef ICPX_STATS
   unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0, st_6 = 0, st_7 = 0;
 #endif
@@ -1621,84 +1570,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
             // (the leaf's records are contiguous, padded past the end, and say themselves
             // whether the triangle counts; all are requested at once, the leaf's own with them)
             const vec4f la_ = lpre4[2 * leaf], lb_ = lpre4[2 * leaf + 1];
-            if constexpr (L == 4)
-            {
-              // four triangles per leaf: their records by component (k_tri_pack4), tested two
-              // at a time with packed fp32 instructions
-              vec4f pk[8];
-#pragma unroll
-              for (int t = 0; t < 8; t++)
-                pk[t] = tpk4[8 * leaf + t];
-              if (la_.w < 0.f)
-                continue; // (no triangle of this leaf can be anybody's closest)
-              const float ux = xf - lb_.x, uy = yf - lb_.y, uz = zf - lb_.z;
-              const float u2 = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-              const float lbl = tri_lb_rec(la_.x, la_.y, la_.z, la_.w, lb_.w, ux, uy, uz, u2, eabs);
-              if (want && lbl > prunef)
-              {
-                want = false;
-                sec2 = fminf(sec2, lbl); // every triangle of the leaf is at least this far
-              }
-              if (__ballot(want) == 0ull)
-                continue;
-              STAT(7, lane == 0 ? 1 : 0);
-              // (every centroid lies in the leaf's sphere: the sum of the magnitudes of the
-              // components of query - centroid is at most that of query - centre plus sqrt(3)
-              // radii, the stored centroids' rounding included)
-              const float l1b = ((fabsf(ux) + fabsf(uy)) + fabsf(uz) +
-                                  1.7320509f * (lb_.w + 2.f * eabs)) * 1.000001f;
-              const float mb = __builtin_fmaf(6.1e-7f, l1b, 4.f * eabs);
-              const float wb = -4.00001f * eabs * l1b;
-              const v2f x2 = { xf, xf }, y2 = { yf, yf }, z2 = { zf, zf };
-              const v2f vxa = x2 - (v2f){ pk[4].x, pk[4].y }, vxb = x2 - (v2f){ pk[4].z, pk[4].w };
-              const v2f vya = y2 - (v2f){ pk[5].x, pk[5].y }, vyb = y2 - (v2f){ pk[5].z, pk[5].w };
-              const v2f vza = z2 - (v2f){ pk[6].x, pk[6].y }, vzb = z2 - (v2f){ pk[6].z, pk[6].w };
-              const v2f q2a = __builtin_elementwise_fma(vza, vza, __builtin_elementwise_fma(vya, vya, vxa * vxa));
-              const v2f q2b = __builtin_elementwise_fma(vzb, vzb, __builtin_elementwise_fma(vyb, vyb, vxb * vxb));
-              // the centroids' distances are upper bounds of the triangles': the smallest met
-              // so far bounds the query's result before anything has been screened
-              float ubn = ubq;
-              ubn = fminf(ubn, pk[3].x < 0.f ? FLT_MAX : q2a.x);
-              ubn = fminf(ubn, pk[3].y < 0.f ? FLT_MAX : q2a.y);
-              ubn = fminf(ubn, pk[3].z < 0.f ? FLT_MAX : q2b.x);
-              ubn = fminf(ubn, pk[3].w < 0.f ? FLT_MAX : q2b.y);
-              if (__ballot(active && ubn < ubq) != 0ull)
-              {
-                if (active && ubn < ubq)
-                {
-                  ubq = ubn;
-                  const float vhi = __builtin_amdgcn_sqrtf(ubn) * 1.000001f + 2.f * eabs;
-                  ubf = vhi * vhi * 1.000001f;
-                  retighten();
-                }
-              }
-              const v2f lba = tri_lb_rec2((v2f){ pk[0].x, pk[0].y }, (v2f){ pk[1].x, pk[1].y },
-                (v2f){ pk[2].x, pk[2].y }, (v2f){ pk[3].x, pk[3].y }, (v2f){ pk[7].x, pk[7].y }, vxa, vya,
-                vza, q2a, mb, wb, eabs);
-              const v2f lbb = tri_lb_rec2((v2f){ pk[0].z, pk[0].w }, (v2f){ pk[1].z, pk[1].w },
-                (v2f){ pk[2].z, pk[2].w }, (v2f){ pk[3].z, pk[3].w }, (v2f){ pk[7].z, pk[7].w }, vxb, vyb,
-                vzb, q2b, mb, wb, eabs);
-#pragma unroll
-              for (int t = 0; t < 4; t++)
-              {
-                const float al = t == 0 ? pk[3].x : t == 1 ? pk[3].y : t == 2 ? pk[3].z : pk[3].w;
-                if (al < 0.f)
-                  continue;
-                STAT(6, lane == 0 ? 1 : 0);
-                const float lb = t == 0 ? lba.x : t == 1 ? lba.y : t == 2 ? lbb.x : lbb.y;
-                if (want && lb > prunef)
-                  sec2 = fminf(sec2, lb); // turned away: at least this far
-                if (want && lb <= prunef && (int32_t)(s0 + t) != hs_used)
-                {
-                  if (npend == 0)
-                    pref = prunef;
-                  pend_s[npend][lane] = (int32_t)(s0 + t);
-                  pend_lb[npend][lane] = pend_encode(lb, pref);
-                  npend++;
-                }
-              }
-              continue;
-            }
             vec4f rec[2 * L];
 #pragma unroll
             for (int t = 0; t < 2 * L; t++)
