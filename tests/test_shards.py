@@ -244,3 +244,24 @@ def test_policy_switches_change_nothing(icpx, synth, oracle):
         for k in ("cell", "dist", "closest"):
             assert np.array_equal(got[k][pick], ref[k]), (n, k)
             assert np.array_equal(again[k][pick], ref2[k]), (n, k)
+    # the cold pass's first bound: Morton curve alone, grid and curve, grid alone; the points
+    # start a hundred edge lengths off the surface, where the three seeds differ most
+    far = synth.apply(synth.rigid(rx=3.0, t=(0.05 * d, 0.02 * d, 0.0)), src[:120_000])
+    ctx3 = icpx.Context(0)
+    ctx3.set_group_width(1)
+    ctx3.set_target(xyz, tri)
+    ctx3.set_source(far)
+    base = None
+    for mode in (1, 0, 2):
+        ctx3.set_seed(mode)
+        ctx3.reset_hints()
+        got = ctx3.correspond(np.eye(4), step=1, max_dist=10.0)
+        if base is None:
+            base = got
+            pick = np.arange(0, len(far), 41)
+            ref = mesh.correspond(far[pick], step=1, max_dist=10.0, grid=True)
+            for k in ("cell", "dist", "closest"):
+                assert np.array_equal(got[k][pick], ref[k]), k
+        else:
+            for k in ("cell", "dist", "closest", "src_index"):
+                assert np.array_equal(got[k], base[k]), (mode, k)
