@@ -103,6 +103,13 @@ extern "C"
    * on the triangles' Morton curve; 0 = the curve's alone; 2 = the grid's alone.  Same results. */
   int icpx_set_seed(icpx_ctx* ctx, int mode);
 
+  /* 1 (default): in a pass that ends in the matrix-core build of the fused sums (clouds up to
+   * four million points), the queries let through on set certificates have their sets weighed
+   * by that kernel's wavefronts ahead of their rows; 0: by
+   * the contested-queries kernel in a launch of its own, as passes that emit rows always do.
+   * Same winners either way.  For measurements. */
+  int icpx_set_weigh(icpx_ctx* ctx, int in_finalize);
+
   /* 1 (default): a cloud of a quarter of a million points or more per rank whose mean residual
    * stays beyond the reach of the shortcut's neighbour lists (a noisy scan) goes by the large
    * cloud's policy whatever its size; 0: the policy goes by size alone.  For measurements. */

@@ -321,6 +321,18 @@ struct icpx_ctx
   int persistent = 4; // tree kernel: 1 pooled lanes, 3 one walk per wavefront, 4 by regime
   int wave_blocks = 19; // blocks per CU of the one-walk-per-wavefront kernel
   int noisy_policy = 1; // a cloud that stays beyond the lists' reach goes by the large cloud's policy (heavy_cloud)
+  // The queries a pass's certificate check lets through on SET certificates have their sets
+  // weighed by the fused finalize itself (query.hpp: weigh_marked) when the pass ends in the
+  // matrix-core build of the sums, whose wavefronts have a few dozen such queries each at most:
+  // a launch less, and k_contested's was as long as its chain of reads (30-45 us a pass on
+  // clouds of one or two million points).  By k_contested otherwise: rows, and the register
+  // build of large clouds, where a wavefront has hundreds of sets to weigh before its first row
+  // and a kernel of its own with more wavefronts in flight does it faster (sixteen million
+  // noisy points: registration 92.4 -> 96.6 ms with the finalize weighing).  0 here: always
+  // k_contested, for measurements.
+  int weigh_in_finalize = 1;
+  bool weigh_later = false; // this pass's searches leave the marked queries to the finalize
+  bool pass_marked = false; // this pass's searches wrote the set mask
   int query_curve = 1;  // the queries' order: 1 along the Hilbert curve, 0 along the Morton curve
   int num_cus = 256;
   // hinted shortcut: per-leaf neighbour lists for one radius, and the residual statistics
@@ -1109,6 +1121,14 @@ extern "C" int icpx_set_seed(icpx_ctx* c, int mode)
   if (mode < 0 || mode > 2)
     return fail(ICPX_E_INVALID, "seed mode must be 0 (curve), 1 (grid and curve) or 2 (grid), got %d", mode);
   c->seed_mode = mode;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_weigh(icpx_ctx* c, int in_finalize)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  c->weigh_in_finalize = in_finalize ? 1 : 0;
   return ICPX_OK;
 }
 
@@ -1921,7 +1941,14 @@ static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, uns
   if (rgrid > 8192)
     rgrid = 8192;
   // (overflows are rare: a bounded number of blocks takes them in turns)
-  launch_ev(c, true, k_contested<L>, rgrid + std::min(grid, 256u), 256, st, a, rgrid);
+  Search3Args ac = a;
+  c->pass_marked = a.setmask != nullptr;
+  if (c->weigh_later)
+  {
+    ac.setmask = nullptr; // (the marked queries' sets are weighed by the finalize that follows)
+    rgrid = std::min(rgrid, 1024u);
+  }
+  launch_ev(c, true, k_contested<L>, rgrid + std::min(grid, 256u), 256, st, ac, rgrid);
 }
 
 // Neighbour lists of every leaf of the one-triangle-per-leaf tree for radius eps (see
@@ -2459,6 +2486,7 @@ static int run_search(icpx_ctx* c)
   c->last_split = false;
   c->lean_base = false;
   c->lean_pairs_pass = false;
+  c->pass_marked = false;
   c->certs_live = c->pass_certs && c->hint_valid; // (what the last pass left)
   c->pass_certs = false;
   const int G = pick_width(c);
@@ -2739,11 +2767,20 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * ICPX_NSUMS, st));
     return ICPX_OK;
   }
+  c->weigh_later = c->weigh_in_finalize != 0 && finalize_on_matrix_core(c, c->nq);
   rc = run_search(c);
+  c->weigh_later = false;
   if (rc)
     return rc;
   FinalArgs f;
   fill_final(c, f, max_dist, min_dot, use_sn, use_sn || metric == ICPX_METRIC_PLANE_TO_PLANE);
+  if (c->weigh_in_finalize && c->pass_marked && finalize_on_matrix_core(c, c->nq))
+  {
+    f.setmask = reinterpret_cast<const unsigned long long*>(c->d_setmask);
+    f.cand = c->d_cand;
+    f.hint_rw = c->d_hint;
+    f.scene_max = c->scene_max;
+  }
   const bool want_stat = stat && !c->stat_pending; // (what the shortcut's policy looks at)
   // one resident round of the build that suits the cloud's size
   int grid = finalize_grid(c, c->nq);

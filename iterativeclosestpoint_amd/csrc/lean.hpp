@@ -303,6 +303,47 @@ __device__ __forceinline__ void lean_weigh_list(const FinalArgs& a, const Xf& T,
   }
 }
 
+// The marked queries (a.setmask: let through on a set certificate by this pass's check) among
+// a wavefront's first + lane, first + stride + lane, ...: listed 64 trips of the rows' loop at a
+// time (every lane reads one trip's mask word), weighed by lean_weigh_list whenever the list is
+// full and at the end.  first and stride are multiples of 64: a trip's queries are one word.
+__device__ __forceinline__ void weigh_marked(const FinalArgs& a, const Xf& T, int64_t first,
+  int64_t stride, int lane, int32_t* list, int cap)
+{
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int64_t words = (a.nq + 63) >> 6, wstride = stride >> 6;
+  int nset = 0;
+  for (int64_t w0 = first >> 6; w0 < words; w0 += 64 * wstride)
+  {
+    const int64_t wi = w0 + (int64_t)lane * wstride;
+    const unsigned long long mine = wi < words ? a.setmask[wi] : 0ull;
+    unsigned long long any = __ballot(mine != 0ull);
+    while (any)
+    {
+      const int trip = __ffsll((long long)any) - 1;
+      any &= any - 1ull;
+      const unsigned long long word = __shfl(mine, trip, 64);
+      const int64_t p = ((w0 + (int64_t)trip * wstride) << 6) + lane;
+      const bool marked = ((word >> lane) & 1ull) != 0ull && p < a.nq;
+      const unsigned long long ms = __ballot(marked);
+      const int cnt = __popcll(ms);
+      if (nset + cnt > cap)
+      {
+        __builtin_amdgcn_wave_barrier(); // (a wavefront's LDS accesses complete in order)
+        lean_weigh_list(a, T, list, nset, lane);
+        __builtin_amdgcn_wave_barrier();
+        nset = 0;
+      }
+      if (marked)
+        list[nset + __popcll(ms & lt)] = (int32_t)p;
+      nset += cnt;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  lean_weigh_list(a, T, list, nset, lane);
+  __builtin_amdgcn_wave_barrier();
+}
+
 // The certificate loop of a lean pass for one wavefront: its queries first + lane, first +
 // stride + lane, ...: each held against its certificate (k_search_local's arithmetic, the
 // anchor's transform Tc); the ones that stand on sets listed for lean_weigh_list (list: room

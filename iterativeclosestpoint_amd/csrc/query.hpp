@@ -324,6 +324,11 @@ struct FinalArgs
   float eps;
   float scene_max;
   int lean_inject; // not zero: the pass fails whatever it finds (tests of the repeat)
+  // not null (the matrix-core sums build only): one bit per query that this pass's certificate check let
+  // through on a SET certificate; the wavefront that makes such a query's row first weighs the
+  // set's members (cand[]) and writes the winner to hint[] (weigh_marked), which is otherwise
+  // k_contested's work in a launch of its own
+  const unsigned long long* setmask;
 };
 
 // (lean.hpp) the certificate loop of a lean pass for one wavefront (queries first + lane,
@@ -331,6 +336,12 @@ struct FinalArgs
 // that have to be worked out written to hint[].  Called by all 64 lanes.
 __device__ __forceinline__ void lean_certify(const FinalArgs& a, const Xf& T, const Xf& Tc,
   bool far_on, int64_t first, int64_t stride, int lane, int32_t* list, bool& lean_bad);
+
+// (lean.hpp) the queries among a wavefront's (first + lane, first + stride + lane, ...) that are
+// marked in a.setmask: their sets weighed, the winners written to hint[].  list: room for `cap`
+// (>= 64) entries in LDS, this wavefront's own.  Called by all 64 lanes.
+__device__ __forceinline__ void weigh_marked(const FinalArgs& a, const Xf& T, int64_t first,
+  int64_t stride, int lane, int32_t* list, int cap);
 
 template <int METRIC>
 struct SumCfg
@@ -691,6 +702,9 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     if (__ballot(lean_bad) != 0ull && lane == 0)
       *a.lean_fail = 1;
   }
+  else if (!ROWS && a.setmask)
+    weigh_marked(a, T, (int64_t)blockIdx.x * FIN_THREADS + (threadIdx.x & ~63), stride, lane,
+      reinterpret_cast<int32_t*>(&feat[wid][0][0]), 1024);
   for (int64_t p0 = (int64_t)blockIdx.x * FIN_THREADS + (threadIdx.x & ~63); p0 < a.nq; p0 += stride)
   {
     const int64_t p = min(p0 + lane, a.nq - 1);

@@ -1879,24 +1879,47 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
       const int64_t q = h0 * 32 + setq[threadIdx.x >> 6][r];
       const d3 x = xform(T, a.qpos + 3 * q);
       const int4 c0 = *reinterpret_cast<const int4*>(a.cand + q * RING3);
-      const int4 c1 = *reinterpret_cast<const int4*>(a.cand + q * RING3 + 4);
-      const int32_t m[RING3] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
       double bd2 = INFINITY;
       int32_t bid = 0x7fffffff, bs = -1;
-#pragma unroll 1
-      for (int i = 0; i < RING3 && m[i] >= 0; i++)
+      // A set of two (most are: a winner and the rival a hair behind it) is screened first: if
+      // the screened distances are farther apart than the tie tolerance the nearer one wins, as
+      // it does for a search that ends with one contender, at a third of the instructions of two
+      // exact evaluations; only a real tie, or a larger set, is evaluated exactly.
+      bool decided = false;
+      if (c0.x >= 0 && c0.y >= 0 && c0.z < 0)
       {
+        d3 A0, A1, A2, B0, B1, B2;
+        load_tri(a.tverts, c0.x, A0, A1, A2);
+        load_tri(a.tverts, c0.y, B0, B1, B2);
+        const double da = tri_d2_screen(x, A0, A1, A2), db = tri_d2_screen(x, B0, B1, B2);
+        const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
+          fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
+        const double rb = sqrt(fmin(da, db)) + 1e-9 * (double)smax;
+        if (fmax(da, db) > rb * rb)
+        {
+          bs = da < db ? c0.x : c0.y;
+          decided = true;
+        }
+      }
+#pragma unroll 1
+      for (int i = 0; i < RING3 && !decided; i++)
+      {
+        // (members read one by one: an array of them indexed by the loop's counter would live
+        // in scratch memory)
+        const int32_t mi = a.cand[q * RING3 + i];
+        if (mi < 0)
+          break;
         d3 P0, P1, P2, cp;
         double dd, w[3];
-        load_tri(a.tverts, m[i], P0, P1, P2);
+        load_tri(a.tverts, mi, P0, P1, P2);
         if (tri_eval(x, P0, P1, P2, cp, dd, w))
         {
-          const int32_t id = a.tid[m[i]];
+          const int32_t id = a.tid[mi];
           if (better(dd, id, bd2, bid))
           {
             bd2 = dd;
             bid = id;
-            bs = m[i];
+            bs = mi;
           }
         }
       }

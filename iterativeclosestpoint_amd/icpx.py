@@ -35,6 +35,7 @@ DEV_SYMBOLS = (
     "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local", "icpx_set_refill",
     "icpx_set_finalize", "icpx_set_lean", "icpx_set_anchor", "icpx_set_shard_order",
     "icpx_set_certify_min", "icpx_set_wave_blocks", "icpx_set_query_curve", "icpx_set_noisy_policy", "icpx_set_seed",
+    "icpx_set_weigh",
 )
 
 
@@ -100,6 +101,7 @@ def load():
     lib.icpx_set_query_curve.argtypes = [vp, ci]
     lib.icpx_set_noisy_policy.argtypes = [vp, ci]
     lib.icpx_set_seed.argtypes = [vp, ci]
+    lib.icpx_set_weigh.argtypes = [vp, ci]
     lib.icpx_run_end.argtypes = [vp, vp, C.POINTER(ci), C.POINTER(dbl), C.POINTER(ci)]
     lib.icpx_last_build_seconds.argtypes = [vp]
     lib.icpx_last_build_seconds.restype = dbl
@@ -336,6 +338,10 @@ class Context:
     def set_seed(self, mode):
         """Cold seeds of the wavefront walk: 0 Morton curve, 1 grid and curve (default), 2 grid."""
         _chk(load().icpx_set_seed(self._h, int(mode)))
+
+    def set_weigh(self, in_finalize):
+        """Sets of certified queries weighed by the fused finalize (1, default) or by k_contested (0)."""
+        _chk(load().icpx_set_weigh(self._h, int(in_finalize)))
 
     def set_noisy_policy(self, enable):
         _chk(load().icpx_set_noisy_policy(self._h, int(enable)))

@@ -180,8 +180,8 @@ def test_policy_switches_change_nothing(icpx, synth, oracle):
     """The host's policy on both sides of each of its boundaries (development switches in place
     of cloud sizes): a noisy scan of 300 000 points registers to the same bits whether its
     certificates are checked by the light kernel or by the shortcut, whether a noisy cloud goes
-    by the large cloud's policy or not, along either curve; the rows at the end are the
-    oracle's.  Then the density rule: a cloud just below and just above a quarter of the
+    by the large cloud's policy or not, along either curve, whether the sets of certified queries
+    are weighed by the fused finalize or by k_contested; the rows at the end are the oracle's.  Then the density rule: a cloud just below and just above a quarter of the
     triangles."""
     xyz, tri = synth.bumpy_torus(300, 150)
     pts, f, fn = synth.sample_surface(xyz, tri, 300_000, seed=11)
@@ -196,13 +196,14 @@ def test_policy_switches_change_nothing(icpx, synth, oracle):
     ctx.set_target(xyz, tri)
     ctx.set_source(src)
     res = {}
-    for name, noisy, cmin, local, curve in (("default", 1, -1, 1, 1), ("by size alone", 0, -1, 1, 1),
-                                             ("large", 1, 100_000, 1, 1), ("light kernel", 1, -1, 3, 1),
-                                             ("morton", 1, -1, 1, 0)):
+    for name, noisy, cmin, local, curve, weigh in (("default", 1, -1, 1, 1, 1), ("by size alone", 0, -1, 1, 1, 1),
+                                                    ("large", 1, 100_000, 1, 1, 1), ("light kernel", 1, -1, 3, 1, 1),
+                                                    ("morton", 1, -1, 1, 0, 1), ("sets by k_contested", 1, -1, 1, 1, 0)):
         ctx.set_local(local)
         ctx.set_noisy_policy(noisy)
         ctx.set_certify_min(cmin)
         ctx.set_query_curve(curve)
+        ctx.set_weigh(weigh)
         before = ctx.debug_stats()
         T, it, mean, st = ctx.run(p)
         after = ctx.debug_stats()
@@ -223,6 +224,7 @@ def test_policy_switches_change_nothing(icpx, synth, oracle):
     ctx.set_noisy_policy(1)
     ctx.set_certify_min(-1)
     ctx.set_query_curve(1)
+    ctx.set_weigh(1)
     rows = ctx.correspond(T0, step=1, max_dist=10.0)
     pick = (np.arange(3_000) * 97 + 3).astype(np.int64)
     mesh = oracle.Mesh(xyz, tri)
