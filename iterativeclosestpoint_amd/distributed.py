@@ -1,14 +1,16 @@
 """Source-sharded registration: one process per GPU, target replicated.
 
 Every rank holds the whole target (its BVH and tables are built independently
-from identical input, so they are identical) and a contiguous block of the kept
-source indices.  One iteration is: local fused search + fp64 partial sums on the
-GPU, ONE all-reduce of the 40-double sum vector (RCCL over xGMI when the process
-group's backend is "nccl"; the message is 320 bytes, so the collective is
-latency-bound and there is exactly one per iteration), then the same O(1) host
-solve on every rank, which keeps the transforms identical without a broadcast.
-The reference has no multi-process path; the loop is vtkICP::InternalUpdate's
-(ICP/vtkICP.cxx:189-246).
+from identical input, so they are identical) and its shard of the kept source
+points: chunks of the kept points' order along a space-filling curve, dealt out
+to the ranks in turn (icpx_set_shard).  One iteration is: local fused search +
+fp64 partial sums on the GPU, ONE all-reduce of the 40-double vector (35 sums
+and 5 job-wide counts the host's policy goes by; RCCL over xGMI when the
+process group's backend is "nccl"; the message is 320 bytes, so the collective
+is latency-bound and there is exactly one per iteration), then the same solve
+on every rank's device, which keeps the transforms identical without a
+broadcast.  The reference has no multi-process path; the loop is
+vtkICP::InternalUpdate's (ICP/vtkICP.cxx:189-246).
 """
 import numpy as np
 

@@ -1,0 +1,93 @@
+"""Development aid: an N-rank job on ONE GPU, in one process.  N contexts (rank r of N each) take
+their shards of the same cloud and run the multi-rank loop (icpx_run_advance / icpx_run_update)
+in turn on one stream, with the all-reduce replaced by a sum of the N sum vectors on the device:
+every rank's solve sees the JOB's sums, as in a real job, so the transform, the policy figures
+and the leftovers are the job's (bench.py --emulate-shard registers one shard by itself).  What
+rank 0's kernels take per registration is timed with events around its share of every pass."""
+import argparse
+import json
+import os
+import sys
+import time
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from iterativeclosestpoint_amd import icpx, synth  # noqa: E402
+from iterativeclosestpoint_amd.distributed import ShardedICP  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c4")
+    ap.add_argument("--ranks", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    a = ap.parse_args()
+    c = {"c3": synth.config_c3, "c4": synth.config_c4,
+         "c5big": lambda: synth.config_c5(nu=1000, nv=500, npts=1_200_000)}[a.workload]()
+    n = a.ranks
+    ranks = [ShardedICP(device=0, rank=r, world=n) for r in range(n)]
+    torch.cuda.synchronize()
+    stream = ranks[0].stream
+    for sh in ranks:
+        sh.ctx.set_stream(stream.cuda_stream)
+        sh.set_target(c["target_xyz"], c["target_tri"])
+        sh.set_source(c["source_xyz"], c["source_normals"])
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks = c["metric"], 50, len(c["source_xyz"])
+    p.max_distance = c["max_dist"]
+    ptrs = [sh.sums_dev.data_ptr() for sh in ranks]
+    out = {"workload": a.workload, "ranks": n, "registrations": []}
+    for rep in range(a.warmup + a.steps):
+        evs = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for sh in ranks:
+            sh.ctx.run_begin(p)
+        passes = 0
+        with torch.cuda.stream(stream):
+            while True:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                alive0 = ranks[0].ctx.run_advance(ptrs[0])
+                e1.record(stream)
+                alive = [alive0] + [sh.ctx.run_advance(ptr) for sh, ptr in zip(ranks[1:], ptrs[1:])]
+                assert all(x == alive0 for x in alive), alive   # every rank decides alike
+                if not alive0:
+                    break
+                total = torch.stack([sh.sums_dev for sh in ranks]).sum(0)   # the "all-reduce"
+                for sh in ranks:
+                    sh.sums_dev.copy_(total)
+                e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e2.record(stream)
+                ranks[0].ctx.run_update(ptrs[0])
+                e3.record(stream)
+                for sh, ptr in zip(ranks[1:], ptrs[1:]):
+                    sh.ctx.run_update(ptr)
+                evs.append((e0, e1, e2, e3))
+                passes += 1
+        res = [sh.ctx.run_end() for sh in ranks]
+        torch.cuda.synchronize()
+        wall = 1e3 * (time.perf_counter() - t0)
+        for r in res[1:]:
+            assert np.array_equal(r[0], res[0][0]) and r[1:] == res[0][1:]   # one transform for all
+        per_pass = [x[0].elapsed_time(x[1]) + x[2].elapsed_time(x[3]) for x in evs]
+        if rep >= a.warmup:
+            out["registrations"].append({
+                "rank0_kernels_ms": round(sum(per_pass), 3),
+                "wall_ms_all_ranks_in_turn": round(wall, 3),
+                "wall_over_ranks_ms": round(wall / n, 3),
+                "passes_enqueued": passes, "iterations": res[0][1], "status": res[0][3],
+                "rank0_pass_ms_first12": [round(v, 3) for v in per_pass[:12]],
+                "rank0_pass_ms_median_last20": round(float(np.median(per_pass[-20:])), 4),
+                "rank0_last_pass_counters": ranks[0].ctx.debug_counters(),
+            })
+    st = ranks[0].ctx.debug_stats()
+    out["rank0_passes"] = {k: v for k, v in st.items() if isinstance(v, (int, float)) and v}
+    out["truth_residual"] = float(np.abs(res[0][0] @ c["truth"] - np.eye(4)).max()) if "truth" in c else None
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
