@@ -103,12 +103,15 @@ extern "C"
    * on the triangles' Morton curve; 0 = the curve's alone; 2 = the grid's alone.  Same results. */
   int icpx_set_seed(icpx_ctx* ctx, int mode);
 
-  /* 1 (default): in a pass that ends in the matrix-core build of the fused sums (clouds up to
-   * four million points), the queries let through on set certificates have their sets weighed
-   * by that kernel's wavefronts ahead of their rows; 0: by
-   * the contested-queries kernel in a launch of its own, as passes that emit rows always do.
-   * Same winners either way.  For measurements. */
-  int icpx_set_weigh(icpx_ctx* ctx, int in_finalize);
+  /* How the queries that a pass's certificate check lets through on SET certificates get their
+   * winners.  Bit 0 (1): in a pass that ends in the matrix-core build of the fused sums (clouds
+   * up to four million points) their sets are weighed by that kernel's wavefronts ahead of
+   * their rows; else by the contested-queries kernel in a launch of its own, as passes that
+   * emit rows always do.  Bit 1 (2): a weighing also records by how much the winner is ahead of
+   * the set's other members, and while that lead outlasts the query's moves the set is not
+   * weighed at all.  Default 3; 0 = every certified set weighed every pass by the kernel of its
+   * own.  Same winners in every mode.  For measurements. */
+  int icpx_set_weigh(icpx_ctx* ctx, int mode);
 
   /* 1 (default): a cloud of a quarter of a million points or more per rank whose mean residual
    * stays beyond the reach of the shortcut's neighbour lists (a noisy scan) goes by the large
@@ -154,10 +157,14 @@ extern "C"
    * this shard: how far the query may still move before its winner is looked at again,
    * 0 = none, negative = how far before something may come within the distance threshold;
    * a positive value whose last mantissa bit is set stands for a set of contenders rather
-   * than a single winner); 6: the library's query order (int32 per query: position -> kept
+   * than a single winner, and the bit above it says that the winner's lead is on record,
+   * array 9); 6: the library's query order (int32 per query: position -> kept
    * index within the shard; arrays 0, 5 and 7 are in this order); 7: the contender sets
    * (8 x int32 per query, Morton positions, -1 ends a shorter set; meaningful for queries
-   * whose certificate stands for a set). */
+   * whose certificate stands for a set); 8: the last pass's list of queries left to the
+   * tree kernels (uint32 each); 9: per query on a set, by how much its winner was ahead of
+   * the set's other members at the last weighing, less the moves since (float; meaningful
+   * where the certificate says so). */
   int icpx_debug_dump(icpx_ctx* ctx, int what, void* out, int64_t count);
 
   /* Forget the winners of the previous search pass.  A pass normally starts each

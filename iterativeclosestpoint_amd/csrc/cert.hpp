@@ -12,21 +12,40 @@ namespace icpx
 
 constexpr int RING3 = 8;
 
-// A positive certificate's last mantissa bit says what stands while it lasts: 0, the single
-// winner; 1, the set of contenders kept in cand[] (a query on an edge or a vertex shared by
-// several triangles has them at the same distance for good): the winner among them is
-// worked out anew every pass by exact evaluation, but no search is needed to know that
-// nobody else is in the race.  (The value gives way by up to two units in the last place.)
-__device__ __forceinline__ float cert_encode(float c, bool set)
+// A positive certificate's last two mantissa bits say what stands while it lasts.  Bit 0: 0, the
+// single winner; 1, the set of contenders kept in cand[] (a query on an edge or a vertex shared
+// by several triangles has them at the same distance for good; a winner with a rival a hair
+// behind it is kept as a set of two): no search is needed to know that nobody else is in the
+// race, and the winner among them is worked out by exact evaluation.  Bit 1 (sets only): the
+// last such weighing found the winner ahead of every other member by the lead on record in
+// lead[] (a distance, worn down by the passes' moves exactly as the certificate is): while that
+// lasts too, not even the weighing is needed, the winner in hint[] stands.  Every maker of a
+// certificate goes through cert_encode without the third argument, so a new set never has a
+// lead on record; only the weighing kernels raise the bit (cert_note_lead).  (The value gives
+// way by up to four units in the last place.)
+__device__ __forceinline__ float cert_encode(float c, bool set, bool lead = false)
 {
   const uint32_t b = __float_as_uint(c);
-  if (!(c > 0.f) || b < 8u)
+  if (!(c > 0.f) || b < 16u)
     return 0.f;
-  return __uint_as_float(((b - 2u) & ~1u) | (set ? 1u : 0u));
+  return __uint_as_float(((b - 4u) & ~3u) | (set ? 1u : 0u) | ((set && lead) ? 2u : 0u));
 }
 __device__ __forceinline__ bool cert_is_set(float c)
 {
   return c > 0.f && (__float_as_uint(c) & 1u) != 0u;
+}
+__device__ __forceinline__ bool cert_has_lead(float c)
+{
+  return c > 0.f && (__float_as_uint(c) & 3u) == 3u;
+}
+// By how much (a distance) the nearest member of a set is ahead of the next one, for lead[]:
+// d1 <= d2 their squared distances (exact or screened), tau the tie tolerance.  While twice the
+// query's move stays below it the exact comparison names the same winner, whatever the ids.
+__device__ __forceinline__ float lead_of(double d1, double d2, double tau)
+{
+  const float l = __double2float_rd(sqrt(d2)) * 0.999999f - __double2float_ru(sqrt(d1)) * 1.000001f -
+    2.1f * (float)tau;
+  return (l > 0.f && l < 1e30f) ? l : 0.f;
 }
 
 // Anchored passes.  While a registration only jitters about its fixed point, the certificates

@@ -304,6 +304,7 @@ struct icpx_ctx
   int seed_mode = 1;            // cold seeds: 0 the Morton curve's, 1 the grid's and the curve's, 2 the grid's
   float4* d_tpre = nullptr;     // per-triangle plane bounds
   float* d_cert = nullptr;      // per query: the shortcut's certificate (see local.hpp)
+  float* d_lead = nullptr;      // per query on a set: its winner's lead over the other members (cert.hpp)
   uint32_t* d_ticket = nullptr; // k_reduce_solve's count of finished blocks (zero between launches)
   float *d_fn = nullptr, *d_en = nullptr, *d_vn = nullptr;
   float4* d_fnpos = nullptr; // {face normal, cell id} by Morton position (the finalize kernels' read)
@@ -330,7 +331,8 @@ struct icpx_ctx
   // and a kernel of its own with more wavefronts in flight does it faster (sixteen million
   // noisy points: registration 92.4 -> 96.6 ms with the finalize weighing).  0 here: always
   // k_contested, for measurements.
-  int weigh_in_finalize = 1;
+  int weigh_in_finalize = 3; // bit 0: as said; bit 1: the winners' leads are kept (cert.hpp), so that a
+                             // set whose winner is clear of its other members is not weighed at all
   bool weigh_later = false; // this pass's searches leave the marked queries to the finalize
   bool pass_marked = false; // this pass's searches wrote the set mask
   int query_curve = 1;  // the queries' order: 1 along the Hilbert curve, 0 along the Morton curve
@@ -700,6 +702,7 @@ static void free_queries(icpx_ctx* c)
   dev_free(&c->d_ovf_best);
   dev_free(&c->d_fallback);
   dev_free(&c->d_cert);
+  dev_free(&c->d_lead);
   dev_free(&c->d_setmask);
   dev_free(&c->d_work);
   c->q_cap = 0;
@@ -990,6 +993,11 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
     src = c->d_fallback; // the last pass's list of queries left to the tree kernel
     bytes = sizeof(uint32_t) * (size_t)std::min<int64_t>(count, c->nq);
   }
+  else if (what == 9 && c->d_lead)
+  {
+    src = c->d_lead; // (meaningful where the certificate's low bits are both set)
+    bytes = sizeof(float) * (size_t)std::min<int64_t>(count, c->nq);
+  }
   if (!src)
     return fail(ICPX_E_INVALID, "nothing to dump");
   HIPCHK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
@@ -1124,11 +1132,13 @@ extern "C" int icpx_set_seed(icpx_ctx* c, int mode)
   return ICPX_OK;
 }
 
-extern "C" int icpx_set_weigh(icpx_ctx* c, int in_finalize)
+extern "C" int icpx_set_weigh(icpx_ctx* c, int mode)
 {
   if (!c)
     return fail(ICPX_E_INVALID, "null context");
-  c->weigh_in_finalize = in_finalize ? 1 : 0;
+  if (mode < 0 || mode > 3)
+    return fail(ICPX_E_INVALID, "weigh mode must be 0..3, got %d", mode);
+  c->weigh_in_finalize = mode;
   return ICPX_OK;
 }
 
@@ -2217,6 +2227,7 @@ static int run_search3(icpx_ctx* c)
     ALLOC(c->d_ovf_best, c->nq);
     ALLOC(c->d_fallback, c->nq);
     ALLOC(c->d_cert, c->nq);
+    ALLOC(c->d_lead, c->nq);
     ALLOC(c->d_setmask, (c->nq + 63) / 64 + 1);
     c->q3_cap = c->nq;
   }
@@ -2286,6 +2297,10 @@ static int run_search3(icpx_ctx* c)
   c->since_cold = c->hint_valid ? c->since_cold + 1 : 0;
   c->pass_certs = c->use_cert && (mode == 1 || (mode == 3 && c->since_cold >= (heavy_cloud(c) ? 3 : 2)));
   a.cert = c->pass_certs ? c->d_cert : nullptr;
+  // (not for a large cloud: of sixteen million noisy points 6 % stand on sets, and 94 % of those are
+  // points nearest to an edge, whose two triangles tie for good; reading the leads cost its
+  // passes more than the few clear winners saved: registration 92.6 -> 94.2 ms)
+  a.lead = (c->pass_certs && (c->weigh_in_finalize & 2) && !large_cloud(c)) ? c->d_lead : nullptr;
   // a kernel that checks every query's certificate runs in this pass (the shortcut or
   // k_certify, or the wavefront walk over the whole cloud): it marks the queries that stand
   // on set certificates for k_contested
@@ -2330,6 +2345,7 @@ static int run_search3(icpx_ctx* c)
       ca.qpos = c->d_qpos;
       ca.nq = c->nq;
       ca.cert = c->d_cert;
+      ca.lead = a.lead;
       ca.T = a.T.T;
       ca.stop = a.T.stop;
       ca.cert_T = la.cert_T;
@@ -2633,6 +2649,7 @@ static int run_catch_up(icpx_ctx* c, int lag_override = -1);
 static void fill_lean(icpx_ctx* c, FinalArgs& f)
 {
   f.cert = c->d_cert;
+  f.lead = ((c->weigh_in_finalize & 2) && !large_cloud(c)) ? c->d_lead : nullptr;
   f.cert_T = c->d_state->cert_T;
   f.cert_ok = &c->d_state->cert_ok;
   f.cert_cap2 = &c->d_state->cert_cap2;
@@ -2767,19 +2784,23 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * ICPX_NSUMS, st));
     return ICPX_OK;
   }
-  c->weigh_later = c->weigh_in_finalize != 0 && finalize_on_matrix_core(c, c->nq);
+  c->weigh_later = (c->weigh_in_finalize & 1) != 0 && finalize_on_matrix_core(c, c->nq);
   rc = run_search(c);
   c->weigh_later = false;
   if (rc)
     return rc;
   FinalArgs f;
   fill_final(c, f, max_dist, min_dot, use_sn, use_sn || metric == ICPX_METRIC_PLANE_TO_PLANE);
-  if (c->weigh_in_finalize && c->pass_marked && finalize_on_matrix_core(c, c->nq))
+  if ((c->weigh_in_finalize & 1) && c->pass_marked && finalize_on_matrix_core(c, c->nq))
   {
     f.setmask = reinterpret_cast<const unsigned long long*>(c->d_setmask);
     f.cand = c->d_cand;
     f.hint_rw = c->d_hint;
     f.scene_max = c->scene_max;
+    f.cert = c->d_cert;
+    f.lead = ((c->weigh_in_finalize & 2) && !large_cloud(c)) ? c->d_lead : nullptr;
+    f.cert_ok = &c->d_state->cert_ok;
+    f.cert_T = c->d_state->cert_T;
   }
   const bool want_stat = stat && !c->stat_pending; // (what the shortcut's policy looks at)
   // one resident round of the build that suits the cloud's size

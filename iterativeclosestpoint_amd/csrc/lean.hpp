@@ -26,27 +26,29 @@ namespace icpx
 
 // The winner among the members of the set a query stands on (c0: the first four).
 __device__ __forceinline__ int32_t lean_weigh(const FinalArgs& a, int64_t p, const int4& c0,
-  const d3& x)
+  const d3& x, bool record = false)
 {
   // The winner is the one k_contested's exact evaluation of all members would name.  A set of
   // two is screened first: if the screened distances are farther apart than the tie tolerance
   // the nearer one is the winner, as it is for a search that ends with one contender; only a
   // real tie, or a larger set, is evaluated exactly.
-  double bd2 = INFINITY;
+  double bd2 = INFINITY, sd2 = INFINITY; // (the best and the second best member's squared distance)
   int32_t bid = 0x7fffffff, bs = -1;
   bool decided = false;
+  const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
+    fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
   if (c0.x >= 0 && c0.y >= 0 && c0.z < 0)
   {
     d3 A0, A1, A2, B0, B1, B2;
     load_tri(a.tverts, c0.x, A0, A1, A2);
     load_tri(a.tverts, c0.y, B0, B1, B2);
     const double da = tri_d2_screen(x, A0, A1, A2), db = tri_d2_screen(x, B0, B1, B2);
-    const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
-      fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
     const double rb = sqrt(fmin(da, db)) + 1e-9 * (double)smax;
     if (fmax(da, db) > rb * rb)
     {
       bs = da < db ? c0.x : c0.y;
+      bd2 = fmin(da, db);
+      sd2 = fmax(da, db);
       decided = true;
     }
   }
@@ -64,15 +66,24 @@ __device__ __forceinline__ int32_t lean_weigh(const FinalArgs& a, int64_t p, con
       double dd, w[3];
       load_tri(a.tverts, mi, P0, P1, P2);
       const int32_t id = a.tid[mi];
-      if (tri_eval(x, P0, P1, P2, cp, dd, w) && better(dd, id, bd2, bid))
+      if (tri_eval(x, P0, P1, P2, cp, dd, w))
       {
-        bd2 = dd;
-        bid = id;
-        bs = mi;
+        if (better(dd, id, bd2, bid))
+        {
+          sd2 = bd2;
+          bd2 = dd;
+          bid = id;
+          bs = mi;
+        }
+        else
+          sd2 = fmin(sd2, dd);
       }
     }
   }
   a.hint_rw[p] = bs;
+  if (record)
+    cert_note_lead(a.cert, a.lead, p, (bs >= 0 && sd2 < INFINITY) ? lead_of(bd2, sd2, 1e-9 * (double)smax) : 0.f,
+      a.cert_ok, a.cert_T, x, a.qpos + 3 * p);
   return bs;
 }
 
@@ -239,8 +250,10 @@ __global__ __launch_bounds__(256) void k_certify_rest(FinalArgs a)
 // distances; farther apart than the tie tolerance, the nearer one wins, as it does for a
 // search that ends with one contender; else both are evaluated exactly, as k_contested does.
 // A larger set is left to one lane (lean_weigh).
+// record (a full pass's weighing, weigh_marked): the winners' leads go on record (cert.hpp); a
+// lean pass leaves certificates and leads as the last full pass left them.
 __device__ __forceinline__ void lean_weigh_list(const FinalArgs& a, const Xf& T, const int32_t* list,
-  int nset, int lane)
+  int nset, int lane, bool record = false)
 {
   const int k = lane & 1;
   for (int e0 = 0; e0 < nset; e0 += 32)
@@ -271,7 +284,12 @@ __device__ __forceinline__ void lean_weigh_list(const FinalArgs& a, const Xf& T,
       const double rb = sqrt(fmin(d, dp)) + 1e-9 * (double)smax;
       tie = !(fmax(d, dp) > rb * rb);
       if (!tie && k == 0)
+      {
         a.hint_rw[p] = d < dp ? ent.y : ent.z;
+        if (record)
+          cert_note_lead(a.cert, a.lead, p, lead_of(fmin(d, dp), fmax(d, dp), 1e-9 * (double)smax),
+            a.cert_ok, a.cert_T, x, a.qpos + 3 * p);
+      }
     }
     if (__ballot(tie) != 0ull)
     {
@@ -296,10 +314,12 @@ __device__ __forceinline__ void lean_weigh_list(const FinalArgs& a, const Xf& T,
         if (ddp < INFINITY && (bs < 0 || better(ddp, idp, dd, id)))
           bs = ent.z;
         a.hint_rw[p] = bs;
+        if (record) // (within the tie tolerance of each other: no lead worth having)
+          cert_note_lead(a.cert, a.lead, p, 0.f, a.cert_ok, a.cert_T, x, a.qpos + 3 * p);
       }
     }
     if (on && ent.w != 0 && k == 0)
-      (void)lean_weigh(a, p, c0, xform(T, a.qpos + 3 * p));
+      (void)lean_weigh(a, p, c0, xform(T, a.qpos + 3 * p), record);
   }
 }
 
@@ -330,7 +350,7 @@ __device__ __forceinline__ void weigh_marked(const FinalArgs& a, const Xf& T, in
       if (nset + cnt > cap)
       {
         __builtin_amdgcn_wave_barrier(); // (a wavefront's LDS accesses complete in order)
-        lean_weigh_list(a, T, list, nset, lane);
+        lean_weigh_list(a, T, list, nset, lane, a.lead != nullptr);
         __builtin_amdgcn_wave_barrier();
         nset = 0;
       }
@@ -340,7 +360,7 @@ __device__ __forceinline__ void weigh_marked(const FinalArgs& a, const Xf& T, in
     }
   }
   __builtin_amdgcn_wave_barrier();
-  lean_weigh_list(a, T, list, nset, lane);
+  lean_weigh_list(a, T, list, nset, lane, a.lead != nullptr);
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -360,7 +380,8 @@ __device__ __forceinline__ void lean_certify(const FinalArgs& a, const Xf& T, co
     const int64_t p = min(p0 + lane, a.nq - 1);
     const float q3[3] = { a.qpos[3 * p], a.qpos[3 * p + 1], a.qpos[3 * p + 2] };
     const float slack = valid ? a.cert[p] : 0.f;
-    bool stands = false;
+    const float leadv = (valid && a.lead) ? a.lead[p] : 0.f; // (with the certificate, not behind it)
+    bool stands = false, led = false;
     if (slack > 0.f || (slack < 0.f && far_on))
     {
       // the move since the anchor
@@ -371,9 +392,11 @@ __device__ __forceinline__ void lean_certify(const FinalArgs& a, const Xf& T, co
       const float left = slack > 0.f ? slack - 2.000001f * mv - 1e-30f
                                      : -slack - 1.000001f * mv - 1e-30f;
       stands = left > 0.f;
+      // (a set whose winner's lead still stands needs no weighing: hint[] has the winner)
+      led = a.lead && cert_has_lead(slack) && leadv - 2.000001f * mv - 1e-30f > 0.f;
     }
     lean_bad = lean_bad || (valid && !stands);
-    const bool isset = stands && cert_is_set(slack);
+    const bool isset = stands && cert_is_set(slack) && !led;
     const unsigned long long ms = __ballot(isset);
     if (ms)
     {

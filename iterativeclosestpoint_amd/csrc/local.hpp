@@ -278,13 +278,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
   // (a whole pass: one round per block, and the query's own reads join the others)
   const int64_t q0 = (int64_t)blockIdx.x * 256 + tid;
   const int64_t qc0 = (!LISTED && q0 < a.nq) ? q0 : 0;
-  float p30[3] = { 0.f, 0.f, 0.f }, slack00 = 0.f;
+  float p30[3] = { 0.f, 0.f, 0.f }, slack00 = 0.f, lead00 = 0.f;
   if (!LISTED)
   {
     p30[0] = a.qpos[3 * qc0];
     p30[1] = a.qpos[3 * qc0 + 1];
     p30[2] = a.qpos[3 * qc0 + 2];
     slack00 = a.cert ? a.cert[qc0] : 0.f;
+    lead00 = (a.cert && a.lead) ? a.lead[qc0] : 0.f; // (with the certificate, not behind it)
   }
   const int32_t stopv = a.T.stop ? *a.T.stop : 0;
   int32_t okv = 0;
@@ -389,11 +390,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
       if (left > 0.f)
       {
         const bool sc = cert_is_set(slack);
-        const float keep = slack > 0.f ? cert_encode(left * 0.9999999f, sc) : -left * 0.9999999f;
+        const bool ld = a.lead && cert_has_lead(slack);
+        const float keep = slack > 0.f ? cert_encode(left * 0.9999999f, sc, ld) : -left * 0.9999999f;
         if (!anchored)
           a.cert[q] = keep;
         certified = keep != 0.f;
         certset = sc && certified;
+        if (certset && ld)
+        {
+          // the winner's lead over the set's other members still stands: no weighing
+          const float ll = lead00 - 2.000001f * mv - 1e-30f;
+          if (ll > 0.f)
+          {
+            certset = false;
+            if (!anchored)
+              a.lead[q] = ll * 0.9999999f;
+          }
+        }
         // (where lean passes are to follow, a single winner's certificate that is nearly
         // used up is made anew here, or as a pair by the tree kernel, while that costs a
         // search among hundreds: the lean passes hold every query against the certificates
@@ -698,6 +711,8 @@ struct CertifyArgs
   int64_t segcap;
   int rounds; // queries per block / 256 (1 .. CERTIFY_ROUNDS)
   unsigned long long* setmask; // one bit per query: passed, and stands on a set certificate
+                               // whose members have to be weighed again
+  float* lead;                 // the leads of sets' winners (Search3Args::lead), or null
   // not null: the failed queries go on this one dense list (length *direct_count), straight
   // for the tree kernels, instead of the segmented one for the shortcut
   uint32_t* direct;
@@ -745,6 +760,7 @@ __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
     const int64_t qc = active ? q : 0;
     const float p3[3] = { c.qpos[3 * qc], c.qpos[3 * qc + 1], c.qpos[3 * qc + 2] };
     const float slack = c.cert[qc];
+    const float leadv = c.lead ? c.lead[qc] : 0.f; // (with the certificate, not behind it)
     bool certified = false, certset = false;
     if (active && cert_on && (slack > 0.f || (slack < 0.f && far_on)))
     {
@@ -759,11 +775,23 @@ __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
       if (left > 0.f)
       {
         const bool sc = cert_is_set(slack);
-        const float keep = slack > 0.f ? cert_encode(left * 0.9999999f, sc) : -left * 0.9999999f;
+        const bool ld = c.lead && cert_has_lead(slack);
+        const float keep = slack > 0.f ? cert_encode(left * 0.9999999f, sc, ld) : -left * 0.9999999f;
         if (!anchored)
           c.cert[q] = keep;
         certified = keep != 0.f;
         certset = sc && certified;
+        if (certset && ld)
+        {
+          // the winner's lead over the set's other members still stands: no weighing
+          const float ll = leadv - 2.000001f * mv - 1e-30f;
+          if (ll > 0.f)
+          {
+            certset = false;
+            if (!anchored)
+              c.lead[q] = ll * 0.9999999f;
+          }
+        }
       }
     }
     const bool todo = active && !certified;

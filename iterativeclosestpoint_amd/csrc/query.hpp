@@ -90,6 +90,24 @@ __device__ __forceinline__ float cert_rebase_at(float c, const int32_t* cert_ok,
   return cert_rebase(c, 2.000002f * mv + 1e-30f);
 }
 
+// A set's weighing has named its winner (cert.hpp): the winner's lead over the set's other
+// members (l, from lead_of; 0: none worth having, a tie) goes on record for query q, stored as a
+// certificate made in this pass is (in an anchored pass: less twice the query's distance from
+// where the anchor has it), and the certificate's second bit says whether there is one.
+__device__ __forceinline__ void cert_note_lead(float* cert, float* lead, int64_t q, float l,
+  const int32_t* cert_ok, const double* __restrict__ cert_T, const d3& x, const float* __restrict__ p)
+{
+  const float c = cert[q];
+  if (!cert_is_set(c))
+    return;
+  const float g = l > 0.f ? cert_rebase_at(l, cert_ok, cert_T, x, p) : 0.f;
+  const uint32_t b = __float_as_uint(c);
+  if (!(g > 0.f) && (b & 2u) == 0u)
+    return; // (a tie, as it was: most sets of a noisy cloud are points nearest to an edge, for good)
+  lead[q] = g;
+  cert[q] = __uint_as_float(g > 0.f ? (b | 2u) : (b & ~2u));
+}
+
 __device__ __forceinline__ void load_tri(
   const float* __restrict__ tverts, int64_t s, d3& P0, d3& P1, d3& P2)
 {
@@ -329,6 +347,9 @@ struct FinalArgs
   // set's members (cand[]) and writes the winner to hint[] (weigh_marked), which is otherwise
   // k_contested's work in a launch of its own
   const unsigned long long* setmask;
+  // the leads of sets' winners (cert.hpp): read by a lean pass's check; written, with the
+  // certificate's second bit, by weigh_marked (null: not kept)
+  float* lead;
 };
 
 // (lean.hpp) the certificate loop of a lean pass for one wavefront (queries first + lane,

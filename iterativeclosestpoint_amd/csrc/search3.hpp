@@ -319,6 +319,11 @@ struct Search3Args
   // one word, set or not: no counter, no list, nothing to clear.  Null in a pass without
   // such a kernel.
   unsigned long long* setmask;
+  // Per query that stands on a set: the lead of the set's winner over its other members, as
+  // the last weighing found it (cert.hpp; valid while the certificate's second bit says so).  A
+  // check that finds the lead still standing does not mark the query: its winner in hint[]
+  // stands without a weighing.  Null: not kept (every certified set is weighed every pass).
+  float* lead;
 };
 
 // the margin a query's search is widened by (see Search3Args::widen_max)
@@ -1239,6 +1244,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     bool active = idx < total;
     const int64_t q = active ? (a.qlist ? (int64_t)a.qlist[idx] : idx) : 0;
     const float slack = (cert_on && active) ? cert[q] : 0.f;
+    const float leadv = (cert_on && active && a.lead) ? a.lead[q] : 0.f; // (with the certificate, not behind it)
     bool isset = false;
     if (__ballot(slack != 0.f) != 0ull)
     {
@@ -1259,12 +1265,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         if (left > 0.f)
         {
           isset = cert_is_set(slack);
-          const float keep = slack > 0.f ? cert_encode(left * 0.9999999f, isset) : -left * 0.9999999f;
+          const bool ld = a.lead && cert_has_lead(slack);
+          const float keep = slack > 0.f ? cert_encode(left * 0.9999999f, isset, ld) : -left * 0.9999999f;
           if (!anchored)
             cert[q] = keep;
           // (a set certificate worn down to nothing: the search runs after all)
           isset = isset && keep > 0.f;
           active = !(keep != 0.f);
+          if (isset && ld)
+          {
+            // the winner's lead over the set's other members still stands: no weighing
+            const float ll = leadv - 2.000001f * mv - 1e-30f;
+            if (ll > 0.f)
+            {
+              isset = false;
+              if (!anchored)
+                a.lead[q] = ll * 0.9999999f;
+            }
+          }
         }
       }
     }
@@ -1793,9 +1811,24 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
         id = a.tid[s];
       }
     }
+    const double mine = d2;
+    const int32_t smine = s;
     group_argmin<8>(d2, id, s);
     if (j == 0)
       a.hint[q] = s;
+    if (a.lead && a.cert)
+    {
+      // (a search that ended with a set: its winner's lead goes on record with the first weighing)
+      const double second = group_min<8>(smine == s ? (double)INFINITY : mine);
+      if (j == 0 && s >= 0)
+      {
+        const d3 x = xform(T, a.qpos + 3 * q);
+        const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
+          fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
+        cert_note_lead(a.cert, a.lead, q, second < INFINITY ? lead_of(d2, second, 1e-9 * (double)smax) : 0.f,
+          a.cert_ok, a.cert_T, x, a.qpos + 3 * q);
+      }
+    }
   }
   // the queries that stand on a set certificate (one bit each in setmask): a wavefront takes
   // SETS_HALVES half words, 512 consecutive queries.  Where many of them are marked (a tenth of a
@@ -1855,9 +1888,23 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
         }
         else
           s = -1;
+        const double mine = d2;
+        const int32_t smine = s;
         group_argmin<8>(d2, id, s);
         if (j == 0 && q >= 0)
           a.hint[q] = s;
+        if (a.lead)
+        {
+          const double second = group_min<8>((smine == s || smine < 0) ? (double)INFINITY : mine);
+          if (j == 0 && q >= 0 && s >= 0)
+          {
+            const d3 x = xform(T, a.qpos + 3 * q);
+            const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
+              fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
+            cert_note_lead(a.cert, a.lead, q, second < INFINITY ? lead_of(d2, second, 1e-9 * (double)smax) : 0.f,
+              a.cert_ok, a.cert_T, x, a.qpos + 3 * q);
+          }
+        }
       }
       continue;
     }
@@ -1879,8 +1926,10 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
       const int64_t q = h0 * 32 + setq[threadIdx.x >> 6][r];
       const d3 x = xform(T, a.qpos + 3 * q);
       const int4 c0 = *reinterpret_cast<const int4*>(a.cand + q * RING3);
-      double bd2 = INFINITY;
+      double bd2 = INFINITY, sd2 = INFINITY; // (the best and the second best member's squared distance)
       int32_t bid = 0x7fffffff, bs = -1;
+      const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
+        fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
       // A set of two (most are: a winner and the rival a hair behind it) is screened first: if
       // the screened distances are farther apart than the tie tolerance the nearer one wins, as
       // it does for a search that ends with one contender, at a third of the instructions of two
@@ -1892,12 +1941,12 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
         load_tri(a.tverts, c0.x, A0, A1, A2);
         load_tri(a.tverts, c0.y, B0, B1, B2);
         const double da = tri_d2_screen(x, A0, A1, A2), db = tri_d2_screen(x, B0, B1, B2);
-        const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
-          fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
         const double rb = sqrt(fmin(da, db)) + 1e-9 * (double)smax;
         if (fmax(da, db) > rb * rb)
         {
           bs = da < db ? c0.x : c0.y;
+          bd2 = fmin(da, db);
+          sd2 = fmax(da, db);
           decided = true;
         }
       }
@@ -1917,13 +1966,19 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
           const int32_t id = a.tid[mi];
           if (better(dd, id, bd2, bid))
           {
+            sd2 = bd2;
             bd2 = dd;
             bid = id;
             bs = mi;
           }
+          else
+            sd2 = fmin(sd2, dd);
         }
       }
       a.hint[q] = bs;
+      if (a.lead)
+        cert_note_lead(a.cert, a.lead, q, (bs >= 0 && sd2 < INFINITY) ? lead_of(bd2, sd2, 1e-9 * (double)smax) : 0.f,
+          a.cert_ok, a.cert_T, x, a.qpos + 3 * q);
     }
     __builtin_amdgcn_wave_barrier();
   }

@@ -216,6 +216,13 @@ class Context:
         _chk(load().icpx_debug_dump(self._h, 5, _p(v), int(n)))
         return v
 
+    def debug_leads(self, n):
+        """Per query on a set: its winner's lead over the set's other members (valid where the
+        certificate's two low mantissa bits are set)."""
+        v = np.zeros(int(n), np.float32)
+        _chk(load().icpx_debug_dump(self._h, 9, _p(v), int(n)))
+        return v
+
     def debug_query_order(self, n):
         """Position in the library's query order -> kept index within the shard."""
         v = np.zeros(int(n), np.int32)
@@ -339,9 +346,10 @@ class Context:
         """Cold seeds of the wavefront walk: 0 Morton curve, 1 grid and curve (default), 2 grid."""
         _chk(load().icpx_set_seed(self._h, int(mode)))
 
-    def set_weigh(self, in_finalize):
-        """Sets of certified queries weighed by the fused finalize (1, default) or by k_contested (0)."""
-        _chk(load().icpx_set_weigh(self._h, int(in_finalize)))
+    def set_weigh(self, mode):
+        """Certified sets: bit 0, weighed by the matrix-core finalize instead of k_contested;
+        bit 1, the winners' leads are kept and clear winners not weighed at all.  Default 3."""
+        _chk(load().icpx_set_weigh(self._h, int(mode)))
 
     def set_noisy_policy(self, enable):
         _chk(load().icpx_set_noisy_policy(self._h, int(enable)))

@@ -1114,7 +1114,9 @@ def test_certificate_is_below_the_true_gap(icpx, synth, local):
     isset = (cert > 0) & ((cert.view(np.uint32) & 1) == 1)  # stands for a set of contenders
     sets = ctx.debug_contender_sets(len(src))
     cell = ctx.debug_cell_ids(len(tri))
-    nsets = 0
+    lead = ctx.debug_leads(len(src))
+    led = (cert > 0) & ((cert.view(np.uint32) & 3) == 3)    # ... whose winner's lead is on record
+    nsets = nled = 0
     # a sample of the queries, in chunks, and every query that stands on a set
     chunks = [np.arange(k0 * 10, k0 * 10 + 500) for k0 in range(0, 4000, 500)]
     chunks.append(np.nonzero(isset)[0][:400])
@@ -1131,10 +1133,16 @@ def test_certificate_is_below_the_true_gap(icpx, synth, local):
             out[cell[members]] = False
             gap[i] = dall[i][out].min() - d[i, 0]
             nsets += 1
+            if led[pos[i]]:
+                # the lead on record: no more than the next member is behind the nearest one
+                dm = np.sort(dall[i][cell[members]])
+                assert 0.0 < lead[pos[i]] <= dm[1] - dm[0] + 1e-15, "a lead exceeds the true one"
+                nled += 1
         assert np.all(cert[pos] <= gap + 1e-12), "a certificate exceeds the true gap"
         worst = max(worst, float((cert[pos] / np.maximum(gap, 1e-300)).max()))
     assert worst <= 1.0 + 1e-9
     assert isset.sum() > 0 and nsets > 0  # (points sampled on the surface: some lie on edges)
+    assert nled > 0 or local == 1           # (pairs with a clear winner: kept where sets of two are)
 
 
 def test_tree_and_far_certificates_are_sound(icpx, synth, oracle):

@@ -181,7 +181,7 @@ def test_policy_switches_change_nothing(icpx, synth, oracle):
     of cloud sizes): a noisy scan of 300 000 points registers to the same bits whether its
     certificates are checked by the light kernel or by the shortcut, whether a noisy cloud goes
     by the large cloud's policy or not, along either curve, whether the sets of certified queries
-    are weighed by the fused finalize or by k_contested; the rows at the end are the oracle's.  Then the density rule: a cloud just below and just above a quarter of the
+    are weighed by the fused finalize or by k_contested, every pass or only when the winner's lead has run out; the rows at the end are the oracle's.  Then the density rule: a cloud just below and just above a quarter of the
     triangles."""
     xyz, tri = synth.bumpy_torus(300, 150)
     pts, f, fn = synth.sample_surface(xyz, tri, 300_000, seed=11)
@@ -196,9 +196,12 @@ def test_policy_switches_change_nothing(icpx, synth, oracle):
     ctx.set_target(xyz, tri)
     ctx.set_source(src)
     res = {}
-    for name, noisy, cmin, local, curve, weigh in (("default", 1, -1, 1, 1, 1), ("by size alone", 0, -1, 1, 1, 1),
-                                                    ("large", 1, 100_000, 1, 1, 1), ("light kernel", 1, -1, 3, 1, 1),
-                                                    ("morton", 1, -1, 1, 0, 1), ("sets by k_contested", 1, -1, 1, 1, 0)):
+    for name, noisy, cmin, local, curve, weigh in (("default", 1, -1, 1, 1, 3), ("by size alone", 0, -1, 1, 1, 3),
+                                                    ("large", 1, 100_000, 1, 1, 3), ("light kernel", 1, -1, 3, 1, 3),
+                                                    ("morton", 1, -1, 1, 0, 3), ("every set weighed by k_contested", 1, -1, 1, 1, 0),
+                                                    ("every set weighed by the finalize", 1, -1, 1, 1, 1),
+                                                    ("leads kept, k_contested", 1, -1, 1, 1, 2),
+                                                    ("large, no leads", 1, 100_000, 1, 1, 0)):
         ctx.set_local(local)
         ctx.set_noisy_policy(noisy)
         ctx.set_certify_min(cmin)
@@ -224,7 +227,7 @@ def test_policy_switches_change_nothing(icpx, synth, oracle):
     ctx.set_noisy_policy(1)
     ctx.set_certify_min(-1)
     ctx.set_query_curve(1)
-    ctx.set_weigh(1)
+    ctx.set_weigh(3)
     rows = ctx.correspond(T0, step=1, max_dist=10.0)
     pick = (np.arange(3_000) * 97 + 3).astype(np.int64)
     mesh = oracle.Mesh(xyz, tri)

@@ -31,6 +31,15 @@ bits = cert.view(np.uint32)
 print("certificates: none %d, hopeless mark %d, positive single %d, positive set %d, far %d" % (
     (bits == 0).sum(), (bits == 4).sum(), ((cert > 0) & (bits & 1 == 0) & (bits != 4)).sum(),
     ((cert > 0) & (bits & 1 == 1)).sum(), (cert < 0).sum()))
+isset = (cert > 0) & (bits & 1 == 1)
+led = isset & (bits & 3 == 3)
+lead = ctx.debug_leads(n)
+print("sets %d, of which with the winner's lead on record %d (median lead %.2e, 1 %% %.2e); sets without: %d" % (
+    isset.sum(), led.sum(), np.median(lead[led]) if led.any() else 0.0,
+    np.percentile(lead[led], 1) if led.any() else 0.0, (isset & ~led).sum()))
+sets = ctx.debug_contender_sets(n)
+size = np.where((sets < 0).any(1), np.argmax(sets < 0, 1), 8)
+print("members of the sets without a lead:", np.bincount(size[isset & ~led], minlength=9)[2:], " with:", np.bincount(size[led], minlength=9)[2:])
 pos = cert[(cert > 0) & (bits != 4)]
 print("positive certificates: percentiles 1 %.2e 10 %.2e 50 %.2e" % tuple(np.percentile(pos, [1, 10, 50])))
 far = -cert[cert < 0]
