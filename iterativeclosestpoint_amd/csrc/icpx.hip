@@ -1916,6 +1916,7 @@ static int ensure_bin(icpx_ctx* c, int L)
 }
 
 static bool heavy_cloud(const icpx_ctx* c);
+static bool leads_kept(const icpx_ctx* c);
 
 template <int L>
 static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, unsigned pgrid,
@@ -2071,6 +2072,12 @@ static int64_t density_nq(const icpx_ctx* c)
 static bool large_cloud(const icpx_ctx* c)
 {
   return c->certify_min >= 0 && policy_nq(c) >= c->certify_min;
+}
+// Whether the leads of sets' winners are kept (cert.hpp): by the cloud's size itself, whatever
+// kernel checks its certificates.
+static bool leads_kept(const icpx_ctx* c)
+{
+  return policy_nq(c) < CERTIFY_MIN;
 }
 // A cloud whose passes take long enough for the host to stay one pass behind the device in
 // the first passes of a run, so that it knows how the first solve went before it picks the
@@ -2297,10 +2304,10 @@ static int run_search3(icpx_ctx* c)
   c->since_cold = c->hint_valid ? c->since_cold + 1 : 0;
   c->pass_certs = c->use_cert && (mode == 1 || (mode == 3 && c->since_cold >= (heavy_cloud(c) ? 3 : 2)));
   a.cert = c->pass_certs ? c->d_cert : nullptr;
-  // (not for a large cloud: of sixteen million noisy points 6 % stand on sets, and 94 % of those are
+  // (not for a cloud of four million points or more: of sixteen million noisy points 6 % stand on sets, and 94 % of those are
   // points nearest to an edge, whose two triangles tie for good; reading the leads cost its
   // passes more than the few clear winners saved: registration 92.6 -> 94.2 ms)
-  a.lead = (c->pass_certs && (c->weigh_in_finalize & 2) && !large_cloud(c)) ? c->d_lead : nullptr;
+  a.lead = (c->pass_certs && (c->weigh_in_finalize & 2) && leads_kept(c)) ? c->d_lead : nullptr;
   // a kernel that checks every query's certificate runs in this pass (the shortcut or
   // k_certify, or the wavefront walk over the whole cloud): it marks the queries that stand
   // on set certificates for k_contested
@@ -2649,7 +2656,7 @@ static int run_catch_up(icpx_ctx* c, int lag_override = -1);
 static void fill_lean(icpx_ctx* c, FinalArgs& f)
 {
   f.cert = c->d_cert;
-  f.lead = ((c->weigh_in_finalize & 2) && !large_cloud(c)) ? c->d_lead : nullptr;
+  f.lead = ((c->weigh_in_finalize & 2) && leads_kept(c)) ? c->d_lead : nullptr;
   f.cert_T = c->d_state->cert_T;
   f.cert_ok = &c->d_state->cert_ok;
   f.cert_cap2 = &c->d_state->cert_cap2;
@@ -2798,7 +2805,7 @@ static int enqueue_pass(icpx_ctx* c, int metric, int64_t step, double max_dist, 
     f.hint_rw = c->d_hint;
     f.scene_max = c->scene_max;
     f.cert = c->d_cert;
-    f.lead = ((c->weigh_in_finalize & 2) && !large_cloud(c)) ? c->d_lead : nullptr;
+    f.lead = ((c->weigh_in_finalize & 2) && leads_kept(c)) ? c->d_lead : nullptr;
     f.cert_ok = &c->d_state->cert_ok;
     f.cert_T = c->d_state->cert_T;
   }
