@@ -270,3 +270,57 @@ def test_policy_switches_change_nothing(icpx, synth, oracle):
         else:
             for k in ("cell", "dist", "closest", "src_index"):
                 assert np.array_equal(got[k], base[k]), (mode, k)
+
+
+def _job_in_turn(icpx, ranks, p):
+    """The ranks of a job run in turn on the one GPU (one stream), the all-reduce replaced by a
+    sum of their vectors on the device; every rank must decide alike."""
+    stream = ranks[0].stream
+    for sh in ranks:
+        sh.ctx.set_stream(stream.cuda_stream)
+        sh.ctx.run_begin(p)
+    ptrs = [sh.sums_dev.data_ptr() for sh in ranks]
+    passes = 0
+    with torch.cuda.stream(stream):
+        while True:
+            alive = [sh.ctx.run_advance(ptr) for sh, ptr in zip(ranks, ptrs)]
+            assert all(a == alive[0] for a in alive), alive
+            if not alive[0]:
+                break
+            total = torch.stack([sh.sums_dev for sh in ranks]).sum(0)
+            for sh, ptr in zip(ranks, ptrs):
+                sh.sums_dev.copy_(total)
+                sh.ctx.run_update(ptr)
+            passes += 1
+            assert passes < 1000
+    return [sh.ctx.run_end() for sh in ranks]
+
+
+@pytest.mark.parametrize("npts,world,metric", [(10, 16, 1), (5, 3, 1), (7, 4, 0), (2000, 3, 2), (70_000, 5, 1)])
+def test_job_in_one_process_with_small_and_empty_shards(icpx, synth, npts, world, metric):
+    """A job of several ranks, some of which get a handful of points or none (ten points over
+    sixteen ranks), run in turn in this process with the job's sums behind every solve: every
+    rank ends with the same transform, iteration count and status, and they are the one-rank
+    run's (to rounding: the shards' sums add up in another order); too few rows for the metric
+    stop all ranks alike."""
+    from iterativeclosestpoint_amd.distributed import ShardedICP
+    c = synth.config_c3(nu=120, nv=60, npts=max(npts, 16))
+    src, sn = c["source_xyz"][:npts], c["source_normals"][:npts]
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = metric, 12, npts, c["max_dist"]
+    one = icpx.Context(0)
+    one.set_target(c["target_xyz"], c["target_tri"])
+    one.set_source(src, sn)
+    ref = one.run(p)
+    ranks = [ShardedICP(device=0, rank=r, world=world) for r in range(world)]
+    torch.cuda.synchronize()
+    for sh in ranks:
+        sh.set_target(c["target_xyz"], c["target_tri"])
+        sh.set_source(src, sn)
+    res = _job_in_turn(icpx, ranks, p)
+    for r in res[1:]:
+        assert np.array_equal(r[0], res[0][0]) and r[1:] == res[0][1:]
+    assert res[0][1] == ref[1] and res[0][3] == ref[3]
+    assert rel_err(res[0][0], ref[0]) <= 1e-9
+    if npts == 5:
+        assert ref[3] == 2 and ref[1] == 0    # five rows are too few for the six unknowns: nothing is solved
