@@ -255,6 +255,23 @@ __global__ __launch_bounds__(256) void k_certify_rest(FinalArgs a)
 __device__ __forceinline__ void lean_weigh_list(const FinalArgs& a, const Xf& T, const int32_t* list,
   int nset, int lane, bool record = false)
 {
+  if (nset > 32)
+  {
+    // many sets (a noisy cloud: a sixteenth of its points are nearest to an edge or stand on
+    // pairs): a lane per set, its members one after the other, so that a wavefront's few dozen
+    // are one round of reads long, not two
+    for (int e0 = 0; e0 < nset; e0 += 64)
+    {
+      const int e = e0 + lane;
+      if (e < nset)
+      {
+        const int64_t p = list[e];
+        (void)lean_weigh(a, p, *reinterpret_cast<const int4*>(a.cand + p * RING3), xform(T, a.qpos + 3 * p),
+          record);
+      }
+    }
+    return;
+  }
   const int k = lane & 1;
   for (int e0 = 0; e0 < nset; e0 += 32)
   {

@@ -396,17 +396,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
           a.cert[q] = keep;
         certified = keep != 0.f;
         certset = sc && certified;
-        if (certset && ld)
-        {
-          // the winner's lead over the set's other members still stands: no weighing
-          const float ll = lead00 - 2.000001f * mv - 1e-30f;
-          if (ll > 0.f)
-          {
-            certset = false;
-            if (!anchored)
-              a.lead[q] = ll * 0.9999999f;
-          }
-        }
+        // (the winner's lead over the set's other members still stands: no weighing)
+        if (certset && ld && cert_lead_stands(a.lead, q, lead00, mv, anchored))
+          certset = false;
         // (where lean passes are to follow, a single winner's certificate that is nearly
         // used up is made anew here, or as a pair by the tree kernel, while that costs a
         // search among hundreds: the lean passes hold every query against the certificates
@@ -781,17 +773,9 @@ __global__ __launch_bounds__(256) void k_certify(CertifyArgs c)
           c.cert[q] = keep;
         certified = keep != 0.f;
         certset = sc && certified;
-        if (certset && ld)
-        {
-          // the winner's lead over the set's other members still stands: no weighing
-          const float ll = leadv - 2.000001f * mv - 1e-30f;
-          if (ll > 0.f)
-          {
-            certset = false;
-            if (!anchored)
-              c.lead[q] = ll * 0.9999999f;
-          }
-        }
+        // (the winner's lead over the set's other members still stands: no weighing)
+        if (certset && ld && cert_lead_stands(c.lead, q, leadv, mv, anchored))
+          certset = false;
       }
     }
     const bool todo = active && !certified;

@@ -91,21 +91,41 @@ __device__ __forceinline__ float cert_rebase_at(float c, const int32_t* cert_ok,
 }
 
 // A set's weighing has named its winner (cert.hpp): the winner's lead over the set's other
-// members (l, from lead_of; 0: none worth having, a tie) goes on record for query q, stored as a
-// certificate made in this pass is (in an anchored pass: less twice the query's distance from
-// where the anchor has it), and the certificate's second bit says whether there is one.
+// members (l, from lead_of) goes on record for query q, stored as a certificate made in this
+// pass is (in an anchored pass: less twice the query's distance from where the anchor has it),
+// and the certificate's second bit says that there is one.  A tie (l = 0: most sets of a noisy
+// cloud are points nearest to an edge, tied for good) leaves everything as it is and costs
+// nothing: a lead that ran out was zeroed by the check that found it so (cert_lead_stands).
 __device__ __forceinline__ void cert_note_lead(float* cert, float* lead, int64_t q, float l,
   const int32_t* cert_ok, const double* __restrict__ cert_T, const d3& x, const float* __restrict__ p)
 {
-  const float c = cert[q];
-  if (!cert_is_set(c))
+  if (!(l > 0.f))
     return;
-  const float g = l > 0.f ? cert_rebase_at(l, cert_ok, cert_T, x, p) : 0.f;
-  const uint32_t b = __float_as_uint(c);
-  if (!(g > 0.f) && (b & 2u) == 0u)
-    return; // (a tie, as it was: most sets of a noisy cloud are points nearest to an edge, for good)
+  const float g = cert_rebase_at(l, cert_ok, cert_T, x, p);
+  const float c = cert[q];
+  if (!(g > 0.f) || !cert_is_set(c))
+    return;
   lead[q] = g;
-  cert[q] = __uint_as_float(g > 0.f ? (b | 2u) : (b & ~2u));
+  cert[q] = __uint_as_float(__float_as_uint(c) | 2u);
+}
+// The check of a lead on record (ld: the certificate says there is one; leadv: its value; mv:
+// the query's move since the certificates' transform).  Stands: the set needs no weighing, and
+// in a pass that is not anchored the lead is written back less twice the move, as the
+// certificate is.  Ran out: it is zeroed (whatever the pass), so that it can never be held
+// against a later, smaller move; the weighing that follows records a new one if there is one.
+__device__ __forceinline__ bool cert_lead_stands(float* lead, int64_t q, float leadv, float mv,
+  bool anchored)
+{
+  const float ll = leadv - 2.000001f * mv - 1e-30f;
+  if (ll > 0.f)
+  {
+    if (!anchored)
+      lead[q] = ll * 0.9999999f;
+    return true;
+  }
+  if (leadv != 0.f)
+    lead[q] = 0.f;
+  return false;
 }
 
 __device__ __forceinline__ void load_tri(

@@ -1272,17 +1272,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
           // (a set certificate worn down to nothing: the search runs after all)
           isset = isset && keep > 0.f;
           active = !(keep != 0.f);
-          if (isset && ld)
-          {
-            // the winner's lead over the set's other members still stands: no weighing
-            const float ll = leadv - 2.000001f * mv - 1e-30f;
-            if (ll > 0.f)
-            {
-              isset = false;
-              if (!anchored)
-                a.lead[q] = ll * 0.9999999f;
-            }
-          }
+          // (the winner's lead over the set's other members still stands: no weighing)
+          if (isset && ld && cert_lead_stands(a.lead, q, leadv, mv, anchored))
+            isset = false;
         }
       }
     }

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--ranks", type=int, default=8)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--weigh", type=int, default=-1, help="icpx_set_weigh")
     a = ap.parse_args()
     c = {"c3": synth.config_c3, "c4": synth.config_c4,
          "c5big": lambda: synth.config_c5(nu=1000, nv=500, npts=1_200_000)}[a.workload]()
@@ -32,6 +33,8 @@ def main():
     stream = ranks[0].stream
     for sh in ranks:
         sh.ctx.set_stream(stream.cuda_stream)
+        if a.weigh >= 0:
+            sh.ctx.set_weigh(a.weigh)
         sh.set_target(c["target_xyz"], c["target_tri"])
         sh.set_source(c["source_xyz"], c["source_normals"])
     p = icpx.default_params()
