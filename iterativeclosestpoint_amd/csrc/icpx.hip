@@ -2445,8 +2445,12 @@ static int run_search3(icpx_ctx* c)
   c->hint_valid = true;
   // (what a lean pass can follow: the shortcut checked every certificate and whatever was
   // searched again, here or by the tree kernels, got a new one)
+  // (a heavy cloud's pass, k_certify with its list straight to the tree kernels, as well: the
+  // lean kernel reads certificates, sets and winners, never the neighbour lists, which such a
+  // cloud may not have; what it cannot have is k_certify_rest's help, so a query that no search
+  // kernel can certify fails every lean pass there, and the back-off keeps those few)
   c->lean_base = use_local && !c->last_listed && c->pass_certs && mode == 1 && widep != nullptr &&
-    !heavy_cloud(c) && c->nbr_state == 1 && c->d_noff && c->d_nbr;
+    (heavy_cloud(c) ? c->direct : (c->nbr_state == 1 && c->d_noff && c->d_nbr));
   return ICPX_OK;
 }
 
@@ -3521,8 +3525,11 @@ static int run_catch_up(icpx_ctx* c, int lag_override)
     // against)
     const int64_t nq_rec = c->run_shared ? (int64_t)r.nq_total : c->nq;
     // (the few queries that pass left to the tree kernels were given certificates by them)
+    // (a heavy cloud's leftovers are certificates that a cloud still on the move uses up, as many
+    // again next pass, and a lean pass that meets one fails: there the record must show none)
     c->clean_noted = (c->pass_lean[slot] || (c->pass_local[slot] && !c->pass_listed[slot])) &&
-      (int64_t)r.fallback + (int64_t)r.contested <= std::max<int64_t>(16, nq_rec >> 13);
+      (int64_t)r.fallback + (int64_t)r.contested <=
+        (heavy_cloud(c) ? (int64_t)0 : std::max<int64_t>(16, nq_rec >> 13));
     if (r.done)
       c->run_done_known = true;
     note_pass(c, r.n, r.mean, (double)r.fallback, (double)r.listed, c->pass_local[slot],
