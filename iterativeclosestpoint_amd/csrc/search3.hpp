@@ -1412,17 +1412,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
       }
       if ((hs < 0 || stale) && a.seed_grid)
       {
-        // the triangle the query's grid cell names
-        const int32_t gs = a.seed_grid[seed_cell_of(xf, yf, zf, a.box, a.seed_dim)];
-        if (gs >= 0)
+        // the triangles the query's grid cell and its six face neighbours name: the nearest
+        // of seven centroids is worth what a grid of twice the resolution is (cold pass of a
+        // million points 0.95 -> 0.90 ms either way) without its memory and build time; the 26
+        // neighbours cost more reads than they save steps (0.94)
+        const int dim = a.seed_dim;
+        const int64_t cell = seed_cell_of(xf, yf, zf, a.box, dim), plane = (int64_t)dim * dim;
+        const int ix = (int)(cell % dim), iy = (int)((cell / dim) % dim), iz = (int)(cell / plane);
+        int32_t gsn[7];
+        gsn[0] = a.seed_grid[cell];
+        gsn[1] = ix > 0 ? a.seed_grid[cell - 1] : -1;
+        gsn[2] = ix + 1 < dim ? a.seed_grid[cell + 1] : -1;
+        gsn[3] = iy > 0 ? a.seed_grid[cell - dim] : -1;
+        gsn[4] = iy + 1 < dim ? a.seed_grid[cell + dim] : -1;
+        gsn[5] = iz > 0 ? a.seed_grid[cell - plane] : -1;
+        gsn[6] = iz + 1 < dim ? a.seed_grid[cell + plane] : -1;
+#pragma unroll
+        for (int t = 0; t < 7; t++)
         {
-          const float4 rb = a.tpre[2 * (int64_t)gs + 1];
-          const float vx = xf - rb.x, vy = yf - rb.y, vz = zf - rb.z;
-          const float q2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
-          if (q2 < qbest)
+          const int32_t gs = gsn[t];
+          if (gs >= 0 && (t == 0 || gs != gsn[0]))
           {
-            qbest = q2;
-            hs = gs;
+            const float4 rb = a.tpre[2 * (int64_t)gs + 1];
+            const float vx = xf - rb.x, vy = yf - rb.y, vz = zf - rb.z;
+            const float q2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
+            if (q2 < qbest)
+            {
+              qbest = q2;
+              hs = gs;
+            }
           }
         }
       }
