@@ -1753,7 +1753,8 @@ static bool shard_extent(const icpx_ctx* c, int64_t nk, int64_t* k0, int64_t* nq
   return true;
 }
 
-// Kept points of this shard, gathered in Morton order (relative to the target's bounds).
+// Kept points of this shard, gathered in the order of a space-filling curve through the
+// target's bounds (Hilbert's by default, icpx_ctx::query_curve).
 // One rank, or shards by blocks of kept indices: the shard's own points are ordered.  Shards
 // by the curve (the default for several ranks): ALL kept points are ordered (every rank does
 // that for itself, from the same source and the same bounds, with a stable sort: the same
