@@ -554,6 +554,20 @@ __device__ __forceinline__ int gram_slot(int i)
 
 constexpr int FIN_THREADS = 256;
 
+// The block a finalize block stands in for.  Blocks go to the chip's eight XCDs in turn (block b
+// runs on XCD b mod 8, each with an L2 of its own), and a block's stretches of 256 queries
+// are b, b + gridDim, ...: with the blocks taken as they come, neighbouring stretches of the
+// curve order, whose winners are neighbouring triangles that share lines of the triangle
+// records, are read through eight different L2s.  Dealt out this way the blocks of one XCD
+// hold a run of consecutive stretches, and what a stretch shares with its neighbours is
+// fetched from memory once.  Which queries make up which partial sum does not change (block
+// vb's work is done by another block, not another work), so the sums keep their bits.
+__device__ __forceinline__ unsigned fin_block()
+{
+  const unsigned g = gridDim.x, b = blockIdx.x;
+  return (g & 7u) ? b : (b & 7u) * (g >> 3) + (b >> 3);
+}
+
 // Two builds of the fused finalize.  k_finalize keeps the metric's sums in registers (35
 // doubles per lane at most: 168 registers, three wavefronts per SIMD); k_finalize_mx hands
 // the rows to the matrix core (four accumulator registers: 117, four wavefronts per SIMD).
@@ -568,6 +582,7 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
+  const unsigned vb = fin_block();
   constexpr int NS = SumCfg<METRIC>::N;
   double acc[NS];
 #pragma unroll
@@ -575,7 +590,7 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))
     acc[i] = 0.0;
 
   const int64_t stride = (int64_t)gridDim.x * FIN_THREADS;
-  for (int64_t p = (int64_t)blockIdx.x * FIN_THREADS + threadIdx.x; p < a.nq; p += stride)
+  for (int64_t p = (int64_t)vb * FIN_THREADS + threadIdx.x; p < a.nq; p += stride)
   {
     const d3 x = xform(T, a.qpos + 3 * p);
     const int32_t hs = a.hint[p];
@@ -695,7 +710,7 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(3))
       for (int w = 0; w < FIN_THREADS / 64; w++)
         v += red[w][threadIdx.x];
     // (sum-major: the reduction's wavefront then reads 64 consecutive doubles, not one per line)
-    a.partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
+    a.partials[(int64_t)threadIdx.x * gridDim.x + vb] = v;
   }
 }
 
@@ -713,6 +728,7 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(4))
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
+  const unsigned vb = fin_block();
   Xf Tc = T;
   bool far_on = false, lean_bad = false;
   if (LEAN)
@@ -738,15 +754,15 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     // certificates, and the few whose winner has to be worked out (lean.hpp) get it
     // written to hint[], where the rows' loop below finds it.  (In one loop with the rows
     // the rare paths cost every query registers: 55 us a pass instead of 37.)
-    lean_certify(a, T, Tc, far_on, (int64_t)blockIdx.x * FIN_THREADS + (threadIdx.x & ~63), stride,
+    lean_certify(a, T, Tc, far_on, (int64_t)vb * FIN_THREADS + (threadIdx.x & ~63), stride,
       lane, reinterpret_cast<int32_t*>(&feat[wid][0][0]), lean_bad);
     if (__ballot(lean_bad) != 0ull && lane == 0)
       *a.lean_fail = 1;
   }
   else if (!ROWS && a.setmask)
-    weigh_marked(a, T, (int64_t)blockIdx.x * FIN_THREADS + (threadIdx.x & ~63), stride, lane,
+    weigh_marked(a, T, (int64_t)vb * FIN_THREADS + (threadIdx.x & ~63), stride, lane,
       reinterpret_cast<int32_t*>(&feat[wid][0][0]), 1024);
-  for (int64_t p0 = (int64_t)blockIdx.x * FIN_THREADS + (threadIdx.x & ~63); p0 < a.nq; p0 += stride)
+  for (int64_t p0 = (int64_t)vb * FIN_THREADS + (threadIdx.x & ~63); p0 < a.nq; p0 += stride)
   {
     const int64_t p = min(p0 + lane, a.nq - 1);
     const bool valid = p0 + lane < a.nq;
@@ -892,7 +908,7 @@ __global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(4))
         v += (&feat[w][0][0])[slot];
     }
     // (sum-major: the reduction's wavefront then reads 64 consecutive doubles, not one per line)
-    a.partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
+    a.partials[(int64_t)threadIdx.x * gridDim.x + vb] = v;
   }
 }
 

@@ -1799,7 +1799,7 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
-  __shared__ uint16_t setq[4][SETS_HALVES * 32];
+  __shared__ uint32_t setq[4][SETS_HALVES * 32 + 64];
   const int j = threadIdx.x & 7;
   const uint32_t ngroups = nblocks * 32u;
   for (uint32_t r = block * 32u + (threadIdx.x >> 3); r < total; r += ngroups)
@@ -1841,103 +1841,114 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
     }
   }
   // the queries that stand on a set certificate (one bit each in setmask): a wavefront takes
-  // SETS_HALVES half words, 512 consecutive queries.  Where many of them are marked (a tenth of a
-  // noisy cloud stands on sets) every lane weighs the members of its own 32 queries' sets
-  // one after the other (cand[], -1 ends a set of fewer than RING3); where few are (a
-  // thousand of a million), they are dealt out to groups of eight lanes, one member per
-  // lane, so that a pass is one exact evaluation long instead of several in a row.
+  // SETS_HALVES half words, 512 consecutive queries, at a time.  Where many of them are marked
+  // (a fifteenth of a noisy cloud stands on sets) each is weighed by one lane, which takes the
+  // set's members one after the other (cand[], -1 ends a set of fewer than RING3); where few
+  // are (a thousand of a million), they are dealt out to groups of eight lanes, one member
+  // per lane, so that a pass is one exact evaluation long instead of several in a row.
   if (!a.setmask)
     return;
-  for (int64_t h0 = hfirst; h0 < halves; h0 += hstride)
+  // The marked queries of a wavefront's chunks are listed in LDS (their numbers) and weighed
+  // 64 at a time, one to a lane, whatever chunk they came from: a wavefront keeps reading
+  // chunks until it has 64 listed (or has none left to read), so that every round of
+  // evaluations but its last finds all lanes busy.  (One chunk's marked queries at a time
+  // left half the lanes idle on a noisy cloud: 33 of 512 stand on sets there.)
+  int64_t h0 = hfirst;
+  uint32_t npend = 0u; // listed and not yet weighed
+  for (;;)
   {
-    const int64_t h = h0 + lane;
-    uint32_t bits = h0 == hfirst ? bits_first : ((lane < SETS_HALVES && h < halves) ? half[h] : 0u);
-    const uint32_t mine = (uint32_t)__popc(bits);
-    const uint32_t incl = wave_incl_scan(mine, lane);
-    const uint32_t marked = (uint32_t)__shfl((int)incl, 63, 64);
-    if (marked == 0u)
-      continue;
-    if (marked <= SPARSE_SETS)
+    while (npend < 64u && h0 < halves)
     {
-      for (uint32_t r0 = 0; r0 < marked; r0 += 8)
+      const int64_t h = h0 + lane;
+      uint32_t bits = h0 == hfirst ? bits_first : ((lane < SETS_HALVES && h < halves) ? half[h] : 0u);
+      const uint32_t mine = (uint32_t)__popc(bits);
+      const uint32_t incl = wave_incl_scan(mine, lane);
+      const uint32_t marked = (uint32_t)__shfl((int)incl, 63, 64);
+      if (marked != 0u && marked <= SPARSE_SETS && npend == 0u && h0 + hstride >= halves)
       {
-        // the r-th marked query of the wavefront's 2048: the first lane whose running count
-        // exceeds r holds it, as the (r - count before that lane)-th set bit of its word
-        int64_t q = -1;
-        for (uint32_t r = r0; r < marked && r < r0 + 8; r++)
+        // (few, and nothing else to do with them: dealt out to groups of eight lanes)
+        for (uint32_t r0 = 0; r0 < marked; r0 += 8)
         {
-          const int src = __ffsll((long long)__ballot(incl > r)) - 1;
-          const uint32_t isrc = (uint32_t)__shfl((int)incl, src, 64);
-          const uint32_t msrc = (uint32_t)__shfl((int)mine, src, 64);
-          uint32_t bb = (uint32_t)__shfl((int)bits, src, 64);
-          for (uint32_t k = r - (isrc - msrc); k > 0; k--)
-            bb &= bb - 1u;
-          if ((uint32_t)(lane >> 3) == r - r0)
-            q = (h0 + src) * 32 + (__ffs((int)bb) - 1);
-        }
-        int32_t s = q >= 0 ? a.cand[q * RING3 + j] : -1;
-        // members up to the first -1
-        const unsigned long long neg = __ballot(s < 0);
-        const uint32_t negg = (uint32_t)(neg >> (lane & ~7)) & 0xffu;
-        const int cnt = negg ? (__ffs((int)negg) - 1) : RING3;
-        double d2 = INFINITY;
-        int32_t id = 0x7fffffff;
-        if (j < cnt)
-        {
-          const d3 x = xform(T, a.qpos + 3 * q);
-          d3 P0, P1, P2, cp;
-          double dd, w[3];
-          load_tri(a.tverts, s, P0, P1, P2);
-          if (tri_eval(x, P0, P1, P2, cp, dd, w))
+          // the r-th marked query of the wavefront's 2048: the first lane whose running count
+          // exceeds r holds it, as the (r - count before that lane)-th set bit of its word
+          int64_t q = -1;
+          for (uint32_t r = r0; r < marked && r < r0 + 8; r++)
           {
-            d2 = dd;
-            id = a.tid[s];
+            const int src = __ffsll((long long)__ballot(incl > r)) - 1;
+            const uint32_t isrc = (uint32_t)__shfl((int)incl, src, 64);
+            const uint32_t msrc = (uint32_t)__shfl((int)mine, src, 64);
+            uint32_t bb = (uint32_t)__shfl((int)bits, src, 64);
+            for (uint32_t k = r - (isrc - msrc); k > 0; k--)
+              bb &= bb - 1u;
+            if ((uint32_t)(lane >> 3) == r - r0)
+              q = (h0 + src) * 32 + (__ffs((int)bb) - 1);
+          }
+          int32_t s = q >= 0 ? a.cand[q * RING3 + j] : -1;
+          // members up to the first -1
+          const unsigned long long neg = __ballot(s < 0);
+          const uint32_t negg = (uint32_t)(neg >> (lane & ~7)) & 0xffu;
+          const int cnt = negg ? (__ffs((int)negg) - 1) : RING3;
+          double d2 = INFINITY;
+          int32_t id = 0x7fffffff;
+          if (j < cnt)
+          {
+            const d3 x = xform(T, a.qpos + 3 * q);
+            d3 P0, P1, P2, cp;
+            double dd, w[3];
+            load_tri(a.tverts, s, P0, P1, P2);
+            if (tri_eval(x, P0, P1, P2, cp, dd, w))
+            {
+              d2 = dd;
+              id = a.tid[s];
+            }
+            else
+              s = -1;
           }
           else
             s = -1;
-        }
-        else
-          s = -1;
-        const double mine = d2;
-        const int32_t smine = s;
-        group_argmin<8>(d2, id, s);
-        if (j == 0 && q >= 0)
-          a.hint[q] = s;
-        if (a.lead)
-        {
-          const double second = group_min<8>((smine == s || smine < 0) ? (double)INFINITY : mine);
-          if (j == 0 && q >= 0 && s >= 0)
+          const double mine = d2;
+          const int32_t smine = s;
+          group_argmin<8>(d2, id, s);
+          if (j == 0 && q >= 0)
+            a.hint[q] = s;
+          if (a.lead)
           {
-            const d3 x = xform(T, a.qpos + 3 * q);
-            const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
-              fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
-            cert_note_lead(a.cert, a.lead, q, second < INFINITY ? lead_of(d2, second, 1e-9 * (double)smax) : 0.f,
-              a.cert_ok, a.cert_T, x, a.qpos + 3 * q);
+            const double second = group_min<8>((smine == s || smine < 0) ? (double)INFINITY : mine);
+            if (j == 0 && q >= 0 && s >= 0)
+            {
+              const d3 x = xform(T, a.qpos + 3 * q);
+              const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
+                fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
+              cert_note_lead(a.cert, a.lead, q, second < INFINITY ? lead_of(d2, second, 1e-9 * (double)smax) : 0.f,
+                a.cert_ok, a.cert_T, x, a.qpos + 3 * q);
+            }
           }
         }
       }
-      continue;
-    }
-    // many marked: they are listed (their places among the wavefront's 2048, in LDS) and
-    // dealt out one to a lane, so that a lane with five marked queries of its own 32 and a
-    // lane with none end up with the same two or three
-    {
-      uint32_t pos = incl - mine;
-      while (bits)
+      else if (marked != 0u)
       {
-        const int b = __ffs((int)bits) - 1;
-        bits &= bits - 1u;
-        setq[threadIdx.x >> 6][pos++] = (uint16_t)(lane * 32 + b);
+        uint32_t pos = npend + incl - mine;
+        while (bits)
+        {
+          const int b = __ffs((int)bits) - 1;
+          bits &= bits - 1u;
+          setq[threadIdx.x >> 6][pos++] = (uint32_t)(h * 32 + b);
+        }
+        npend += marked;
       }
+      h0 += hstride;
     }
+    if (npend == 0u)
+      break;
     __builtin_amdgcn_wave_barrier(); // (a wavefront's LDS accesses complete in order)
-    for (uint32_t r = (uint32_t)lane; r < marked; r += 64u)
+    const uint32_t take = npend < 64u ? npend : 64u;
+    if ((uint32_t)lane < take)
     {
-      const int64_t q = h0 * 32 + setq[threadIdx.x >> 6][r];
+      const int64_t q = (int64_t)setq[threadIdx.x >> 6][npend - take + (uint32_t)lane];
       const d3 x = xform(T, a.qpos + 3 * q);
       const int4 c0 = *reinterpret_cast<const int4*>(a.cand + q * RING3);
       double bd2 = INFINITY, sd2 = INFINITY; // (the best and the second best member's squared distance)
-      int32_t bid = 0x7fffffff, bs = -1;
+      int32_t bs = -1;
       const float smax = fmaxf(fmaxf(a.scene_max, fabsf((float)x.x)),
         fmaxf(fabsf((float)x.y), fabsf((float)x.z)));
       // A set of two (most are: a winner and the rival a hair behind it) is screened first: if
@@ -1973,12 +1984,16 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
         load_tri(a.tverts, mi, P0, P1, P2);
         if (tri_eval(x, P0, P1, P2, cp, dd, w))
         {
-          const int32_t id = a.tid[mi];
-          if (better(dd, id, bd2, bid))
+          // (cell ids only break exact ties of the squared distance: they are read when one
+          // occurs, not for every member; a scattered four-byte read is a 64-byte line from
+          // memory, and these were a third of what the kernel fetched)
+          bool wins = dd < bd2;
+          if (dd == bd2)
+            wins = a.tid[mi] < (bs >= 0 ? a.tid[bs] : 0x7fffffff);
+          if (wins)
           {
             sd2 = bd2;
             bd2 = dd;
-            bid = id;
             bs = mi;
           }
           else
@@ -1990,6 +2005,7 @@ __device__ __forceinline__ void resolve_ties_body(const Search3Args& a, unsigned
         cert_note_lead(a.cert, a.lead, q, (bs >= 0 && sd2 < INFINITY) ? lead_of(bd2, sd2, 1e-9 * (double)smax) : 0.f,
           a.cert_ok, a.cert_T, x, a.qpos + 3 * q);
     }
+    npend -= take;
     __builtin_amdgcn_wave_barrier();
   }
 }
