@@ -190,13 +190,21 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
 {
   __shared__ double tot[ICPX_NSUMS];
   __shared__ uint32_t last;
+#ifdef ICPX_STATS
+  const unsigned long long rs_t0 = wall_clock64();
+#endif
   // (every block reads the flag before it draws its ticket; the block that draws the last
   // one clears it)
-  const bool failed = lean && *reinterpret_cast<volatile int32_t*>(&s->lean_fail) != 0;
+  // (read whether the pass was a lean one or not: a branch around the read would wait for it
+  // before the reduction's reads go out)
+  const int32_t lean_flag = s->lean_fail;
+  const bool failed = lean && lean_flag != 0;
   // (a lean pass leaves the certificates and the transform they refer to as they are)
-  const bool ran = !failed &&
-    reduce_partials_body(partials, nblocks, sums, &s->done, counters, nullptr, s->T, s->cert_T,
-      lean ? nullptr : &s->cert_ok, cert_mode, cap2, &s->cert_cap2);
+  const bool ran = reduce_partials_body(partials, nblocks, sums, &s->done, counters, nullptr, s->T,
+    s->cert_T, lean ? nullptr : &s->cert_ok, cert_mode, cap2, &s->cert_cap2, 0, 0, nullptr, failed);
+#ifdef ICPX_STATS
+  const unsigned long long rs_t1 = wall_clock64();
+#endif
   if (threadIdx.x == 0)
   {
     __threadfence();
@@ -211,6 +219,11 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
   __syncthreads();
   if (threadIdx.x != 0)
     return;
+#ifdef ICPX_STATS
+  g_rs_stamps[0] = rs_t0;
+  g_rs_stamps[1] = rs_t1;
+  RS_STAMP(2);
+#endif
   *ticket = 0u;
   if (failed)
   {
@@ -1019,6 +1032,12 @@ extern "C" int icpx_stats_read_batches(icpx_ctx* c, unsigned long long out[37])
 {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
+  {
+    unsigned long long rs[8];
+    HIPCHK(hipMemcpyFromSymbol(rs, HIP_SYMBOL(icpx::g_rs_stamps), sizeof(rs)));
+    fprintf(stderr, "k_reduce_solve stamps (10 ns ticks from entry): reduce %llu ticket+totals %llu state reads %llu solve %llu compose %llu publish %llu\n",
+      rs[1] - rs[0], rs[2] - rs[1], rs[4] - rs[2], rs[5] - rs[4], rs[6] - rs[5], rs[7] - rs[6]);
+  }
   HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(icpx::g_stats_batch), sizeof(unsigned long long) * 37));
   unsigned long long z[37] = { 0 };
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(icpx::g_stats_batch), z, sizeof(z)));

@@ -929,11 +929,35 @@ __device__ __forceinline__ bool reduce_partials_body(
   const int32_t* __restrict__ stop, uint32_t* __restrict__ counters, double* __restrict__ stat,
   const double* __restrict__ T, double* __restrict__ cert_T, int32_t* __restrict__ cert_ok,
   int cert_mode, double cap2 = 0.0, double* __restrict__ cert_cap2 = nullptr, int share = 0,
-  int64_t nq = 0, const int32_t* __restrict__ lean_fail = nullptr)
+  int64_t nq = 0, const int32_t* __restrict__ lean_fail = nullptr, bool skip = false)
 {
-  if (stop && *stop)
-    return false; // the pass did not run
   const int i = blockIdx.x, l = threadIdx.x;
+  // (a lane's partials are requested sixteen at a time, ahead of the flags that say whether
+  // the pass ran at all, and added in the order they always were: one after the other each
+  // waits a trip to the other XCDs' memory side, 16 x 0.35 us for the 1024 blocks of a
+  // million points, a third of the whole launch)
+  const double* const mine = partials + (int64_t)i * nblocks;
+  double t[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    t[k] = mine[min(l + 64 * k, nblocks - 1)]; // (no branch around a read: all sixteen go out together)
+  const bool stopped = stop && *stop;
+  // (block 0's counters with them: it has the most to do after the flags and is the one the
+  // others wait for)
+  uint32_t c_old = 0u, c_len = 0u;
+  if (counters && i == 0)
+  {
+    c_old = counters[l & 3];
+    c_len = counters[16 + (l & 31) * 64];
+  }
+  asm volatile("" : "+v"(c_old), "+v"(c_len));
+  // (the values are asked for here, so that the compiler cannot move the reads behind the test
+  // of the flags: reads and flags are then one trip to memory, not one after the other)
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    asm volatile("" : "+v"(t[k]));
+  if (stopped || skip)
+    return false; // the pass did not run, or its sums are worth nothing
   // share: the loop of several ranks.  The spare slots of the vector carry this rank's policy
   // figures through the all-reduce (state.hpp: SLOT_*): the query count and the lean pass's
   // flag from their own blocks, the three counts from block 0, which moves the counters.
@@ -962,7 +986,7 @@ __device__ __forceinline__ bool reduce_partials_body(
   {
     // the search kernels' four pass counters move up for whoever wants to look at them,
     // and are left at zero for the next pass
-    old = counters[l];
+    old = c_old;
     counters[4 + l] = old;
     counters[l] = 0u;
     if (stat && l == 3)
@@ -980,7 +1004,7 @@ __device__ __forceinline__ bool reduce_partials_body(
   {
     // the lengths of the segments of k_certify's list: their sum moves up beside the other
     // counts, and they are left at zero
-    uint32_t len = l < 32 ? counters[16 + l * 64] : 0u;
+    uint32_t len = l < 32 ? c_len : 0u;
     if (l < 32)
       counters[16 + l * 64] = 0u;
     if (l < XPOOLS)
@@ -1005,8 +1029,21 @@ __device__ __forceinline__ bool reduce_partials_body(
     stat[3] = 0.0;
   }
   double v = 0.0;
-  for (int b = l; b < nblocks; b += 64)
-    v += partials[(int64_t)i * nblocks + b];
+  for (int b0 = l; b0 < nblocks; b0 += 64 * 16)
+  {
+    if (b0 != l)
+    {
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        t[k] = mine[min(b0 + 64 * k, nblocks - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+      const double w = v + t[k];
+      v = (b0 + 64 * k < nblocks) ? w : v;
+    }
+  }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1)
     v += __shfl_xor(v, m, 64);

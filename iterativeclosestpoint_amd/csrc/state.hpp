@@ -62,6 +62,12 @@ __device__ __host__ inline uint32_t slot_count(double v)
 // the length of k_certify's list in that pass; contested_now: its tie and overflow lists.
 // (Everything the step reads is requested at once and the record is written from
 // registers: one lane's chain of dependent reads is what this costs.)
+#ifdef ICPX_STATS
+__device__ unsigned long long g_rs_stamps[8];
+#define RS_STAMP(i) g_rs_stamps[i] = wall_clock64()
+#else
+#define RS_STAMP(i)
+#endif
 __device__ inline void solve_and_publish(RunState* s, const double* __restrict__ sums, int metric,
   const double* origin, int check_mean, double max_mean, bool ran, uint32_t fallback_now,
   uint32_t listed_now, uint32_t contested_now, RunRecord* rec, uint32_t seq, float src_rmax = 0.f,
@@ -79,7 +85,9 @@ __device__ inline void solve_and_publish(RunState* s, const double* __restrict__
     fallback = fallback_now;
     s->fallback = fallback;
     double M[16];
+    RS_STAMP(4);
     const int rc = icpx_core::solve_moments(metric, sums, origin, M, &n, &mean);
+    RS_STAMP(5);
     s->mean = mean;
     s->n = n;
     if (check_mean && n > 0.0 && mean <= max_mean)
@@ -130,6 +138,7 @@ __device__ inline void solve_and_publish(RunState* s, const double* __restrict__
       s->anchored = 0;
     }
   }
+  RS_STAMP(6);
   rec->mean = mean;
   rec->n = n;
   rec->iters = iters;
@@ -141,6 +150,7 @@ __device__ inline void solve_and_publish(RunState* s, const double* __restrict__
   rec->nq_total = nq_total;
   __threadfence_system();
   *reinterpret_cast<volatile uint32_t*>(&rec->seq) = seq;
+  RS_STAMP(7);
 }
 
 } // namespace icpx
