@@ -56,6 +56,8 @@ def make_workload(name, rank, synth, own_scan):
         c = synth.config_c4()
     elif name == "c5big":  # partial overlap and 20 % outliers at C3's size
         c = synth.config_c5(nu=1000, nv=500, npts=1_200_000)
+    elif name == "c6":  # a graded mesh at C3's size (edge lengths over a range of 65)
+        c = synth.config_c6()
     elif name == "c3small":  # for quick functional runs only
         c = synth.config_c3(nu=200, nv=100, npts=50_000)
     else:
@@ -124,6 +126,8 @@ def run_workload(args, name, steps, warmup, strong, emu, rank, world, local, col
         sh.ctx.set_noisy_policy(args.noisy_policy)
     if args.curve >= 0:
         sh.ctx.set_query_curve(args.curve)
+    if args.bail >= 0:
+        sh.ctx.set_bail(args.bail)
     sh.set_target(c["target_xyz"], c["target_tri"])
     sh.set_source(c["source_xyz"], c["source_normals"])
     build_s = sh.ctx.build_seconds
@@ -413,6 +417,7 @@ def main():
     ap.add_argument("--lean", type=int, default=-1, help="development: icpx_set_lean")
     ap.add_argument("--noisy-policy", type=int, default=-1, help="development: icpx_set_noisy_policy")
     ap.add_argument("--curve", type=int, default=-1, help="development: icpx_set_query_curve")
+    ap.add_argument("--bail", type=int, default=-1, help="development: icpx_set_bail")
     ap.add_argument("--dump-passes", action="store_true",
                     help="development: the search kernels' median time of every pass into config")
     ap.add_argument("--timing-every", type=int, default=4,

@@ -58,6 +58,15 @@ extern "C"
    * Same results. */
   int icpx_set_refill(icpx_ctx* ctx, int lanes);
 
+  /* Whole passes of the wavefront walk: after how many microseconds of walking a batch of 64
+   * queries is given up on and its queries are searched one wavefront each instead (a few
+   * queries beside a patch of triangles much smaller than their distance from it keep their
+   * whole batch walking for as long as the rest of the pass takes).  1 (default) = on targets
+   * whose triangles' sizes range widely (median longest edge over 2nd percentile of the
+   * shortest above 8), a time that goes by the cloud's size (800 us at least); 0 = never; any
+   * other value = on every target, that many.  Same results. */
+  int icpx_set_bail(icpx_ctx* ctx, int microseconds);
+
   /* The fused finalize: 0 (default) = by the size of the cloud; 1 = the build that keeps the
    * metric's sums in registers; 2 = the build that accumulates them on the matrix core
    * (v_mfma_f64_16x16x4_f64 over a 16-vector per row).  The two add the rows up in different

@@ -354,10 +354,15 @@ struct icpx_ctx
   // of the previous pass that choose the radius
   int use_local = 1;
   int refill_override = 0; // pooled kernels' refill threshold (0 = by regime)
+  int bail_mode = 1;       // whole passes of the wavefront walk give up on long batches: 0 never,
+                           // 1 on a target whose triangles' sizes range widely, after a time that goes by
+                           // the cloud's size, else always, after that many microseconds
   int finalize_build = 0;  // fused finalize: 0 by size, 1 register sums, 2 matrix core
   int nbr_state = 0;    // 0 not tried, 1 built, -1 not worth it for this mesh
   float nbr_eps = 0.f;  // radius the lists cover
   float mesh_edge = 0.f; // typical edge length of the target (sampled)
+  float mesh_grading = 1.f; // median longest edge over 2nd percentile of the shortest (sampled)
+  int64_t bail_passes = 0;  // whole passes of the wavefront walk run by the build that can give up on batches
   uint32_t* d_noff = nullptr;
   int32_t* d_nbr = nullptr;
   uint4* d_qbox = nullptr; // quantised leaf boxes of the one-triangle-per-leaf tree
@@ -974,11 +979,11 @@ extern "C" int icpx_debug_dump(icpx_ctx* c, int what, void* out, int64_t count)
   }
   else if (what == 4)
   {
-    int64_t v[14] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
+    int64_t v[16] = { c->local_passes, c->tree_passes, c->nbr_builds, (int64_t)(c->nbr_eps * 1e9f),
       c->nbr_total, c->certify_passes, c->split_passes, c->split_wave, c->split_pool,
       c->last_flips, c->direct_passes, c->lean_passes, c->lean_failures,
-      c->last_unorientable ? 1 : 0 };
-    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 14));
+      c->last_unorientable ? 1 : 0, (int64_t)(c->mesh_grading * 1e3f), c->bail_passes };
+    std::memcpy(out, v, sizeof(int64_t) * (size_t)std::min<int64_t>(count, 16));
     return ICPX_OK;
   }
   else if (what == 3 && c->d_ovf_best)
@@ -1079,6 +1084,16 @@ extern "C" int icpx_set_refill(icpx_ctx* c, int lanes)
   if (lanes < 0 || lanes > 64)
     return fail(ICPX_E_INVALID, "refill threshold must be 0 (by regime) or 1..64 lanes (got %d)", lanes);
   c->refill_override = lanes;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_bail(icpx_ctx* c, int steps /* microseconds */)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  if (steps < 0)
+    return fail(ICPX_E_INVALID, "microseconds must be 0 (never), 1 (by the cloud's size) or a count (got %d)", steps);
+  c->bail_mode = steps;
   return ICPX_OK;
 }
 
@@ -1302,19 +1317,41 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
     c->bounds_length = std::sqrt(l2);
   }
   {
-    // typical edge length, from an even sample of the triangles (sizes the neighbour lists)
+    // typical edge length, from an even sample of the triangles (sizes the neighbour lists),
+    // and how widely the triangles' sizes range: the median of the sampled triangles' longest
+    // edges over the 2nd percentile of their shortest (an evenly meshed surface: 2 to 4; a
+    // decimated or graded one: dozens)
     const int64_t stride = std::max<int64_t>(1, nt / 8192);
     double sum = 0.0;
     int64_t cnt = 0;
+    std::vector<float> shortest, longest;
     for (int64_t t = 0; t < nt; t += stride, cnt++)
+    {
+      double emin = INFINITY, emax = 0.0;
       for (int k = 0; k < 3; k++)
       {
         const float* p = xyz + 3 * (int64_t)tri[3 * t + k];
         const float* q = xyz + 3 * (int64_t)tri[3 * t + (k + 1) % 3];
         const double dx = (double)p[0] - q[0], dy = (double)p[1] - q[1], dz = (double)p[2] - q[2];
-        sum += std::sqrt(dx * dx + dy * dy + dz * dz);
+        const double e = std::sqrt(dx * dx + dy * dy + dz * dz);
+        sum += e;
+        emin = std::fmin(emin, e);
+        emax = std::fmax(emax, e);
       }
+      if (emin > 0.0 && std::isfinite(emax))
+      {
+        shortest.push_back((float)emin);
+        longest.push_back((float)emax);
+      }
+    }
     c->mesh_edge = (float)(sum / (3.0 * (double)cnt));
+    c->mesh_grading = 1.f;
+    if (shortest.size() >= 64)
+    {
+      std::nth_element(shortest.begin(), shortest.begin() + shortest.size() / 50, shortest.end());
+      std::nth_element(longest.begin(), longest.begin() + longest.size() / 2, longest.end());
+      c->mesh_grading = longest[longest.size() / 2] / shortest[shortest.size() / 50];
+    }
   }
 
   ALLOC(c->d_xyz, 3 * nv);
@@ -1962,10 +1999,29 @@ static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, uns
   }
   else if (wide && pgrid && mode == 1)
     launch_ev(c, false, k_fallback<L>, pgrid, 256, st, a, *wide);
-  else if (mode == 3 && a.cert)
-    launch_ev(c, false, k_search3w<L, true>, wgrid, 64, st, a);
   else if (mode == 3)
-    launch_ev(c, false, k_search3w<L, false>, wgrid, 64, st, a);
+  {
+    const bool bail = a.bail_ticks && wide;
+    if (a.cert && bail)
+      launch_ev(c, false, k_search3w<L, true, true>, wgrid, 64, st, a);
+    else if (a.cert)
+      launch_ev(c, false, k_search3w<L, true>, wgrid, 64, st, a);
+    else if (bail)
+      launch_ev(c, false, k_search3w<L, false, true>, wgrid, 64, st, a);
+    else
+      launch_ev(c, false, k_search3w<L, false>, wgrid, 64, st, a);
+    if (bail)
+    {
+      // the queries of the batches the walk gave up on, one wavefront each (or the pooled
+      // lanes, should they be many)
+      Search3Args ab = a;
+      ab.qlist = a.bail_list;
+      ab.use_hint = 1;
+      ab.setmask = nullptr;
+      ab.bail_ticks = 0u;
+      launch_ev(c, false, k_fallback<L>, pgrid, 256, st, ab, *wide);
+    }
+  }
   else
     launch_ev(c, false, k_search3p<L>, pgrid, 256, st, a);
   unsigned rgrid = grid / 8 + 1; // (a block of four wavefronts weighs the sets of 2048 queries)
@@ -2106,6 +2162,10 @@ static bool leads_kept(const icpx_ctx* c)
 // the first passes of a run, so that it knows how the first solve went before it picks the
 // third pass's kernels.
 constexpr int64_t CLOSE_FOLLOW_MIN = 262144;
+// From which spread of its triangles' sizes (mesh_grading) a target's whole passes of the
+// wavefront walk may give up on batches.  The benchmark's tori come to 2.7 and 4; a torus
+// whose grid lines are drawn together on one side (edge lengths over a range of 65) to 40.
+constexpr float GRADED_MESH = 8.f;
 // A cloud that gets the large cloud's policy (certificates checked by k_certify, its list
 // straight to the tree kernels, pair certificates, no certificates from the third pass): a
 // large one, and one of some size whose points stay beyond the neighbour lists' reach (a noisy
@@ -2289,6 +2349,8 @@ static int run_search3(icpx_ctx* c)
   a.ovf_list = c->d_ovf_list;
   a.ovf_best = c->d_ovf_best;
   a.qlist = nullptr;
+  a.bail_list = nullptr;
+  a.bail_ticks = 0u;
   a.list_lo = 0;
   a.list_hi = INT64_MAX;
   a.cap2 = c->cap2;
@@ -2427,7 +2489,24 @@ static int run_search3(icpx_ctx* c)
   // the shortcut's leftovers: a short list goes one wavefront per query over the 64-ary tree
   Search2Args wide;
   const Search2Args* widep = nullptr;
-  if (use_local && mode == 1 && c->heaps[4].built)
+  // ... and so do the queries of the batches a whole pass of the wavefront walk gives up on:
+  // a batch may walk for half of what a wavefront's share of the pass comes to at a quarter
+  // of a millisecond per batch (a longer one is what the pass ends up waiting for), 0.8 ms
+  // at least (the longest batch of an evenly meshed million triangles takes about 1 ms)
+  // (only for a target whose triangles' sizes range widely, or when asked for: the kernel
+  // that can give up is a build of its own, 3 % slower on every walk)
+  const bool whole_walk = !use_local && mode == 3 &&
+    (c->bail_mode > 1 || (c->bail_mode == 1 && c->mesh_grading > GRADED_MESH));
+  if (whole_walk && ensure_heap(c, 64) == ICPX_OK)
+  {
+    const uint64_t per_wave = ((uint64_t)c->nq / 64u) / std::max(wgrid, 1u);
+    a.bail_list = c->d_fallback;
+    const uint64_t us = c->bail_mode > 1 ? (uint64_t)c->bail_mode
+                                         : std::min<uint64_t>(std::max<uint64_t>(125u * per_wave, 800u), 1000000u);
+    a.bail_ticks = (uint32_t)(us * 2400u / 64u); // (the shader clock at its 2.4 GHz: a lower clock makes the budget longer)
+    c->bail_passes++;
+  }
+  if (((use_local && mode == 1) || a.bail_ticks) && c->heaps[4].built)
   {
     const Heap& h = c->heaps[4];
     wide.qpos = c->d_qpos;

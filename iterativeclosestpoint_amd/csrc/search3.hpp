@@ -324,6 +324,16 @@ struct Search3Args
   // check that finds the lead still standing does not mark the query: its winner in hint[]
   // stands without a weighing.  Null: not kept (every certified set is weighed every pass).
   float* lead;
+  // A whole pass of the wavefront walk gives up on a batch that has been walking for
+  // bail_ticks x 64 cycles of the shader clock (0: never): its queries go on this list (count in
+  // counters[3]) with the best triangle found so far as their start, and the kernel behind the
+  // walk (k_fallback) serves them one wavefront per query.  A few queries beside a patch of
+  // triangles much smaller than their distance from it have thousands of boxes within their
+  // bound; their batch of 64 then walks for as long as the rest of the pass takes together (a
+  // mesh whose edge lengths range over a factor of 65: 3 500 node steps against a mean of
+  // 100, a cold pass of 15.7 ms instead of 1).
+  uint32_t* bail_list;
+  uint32_t bail_ticks;
 };
 
 // the margin a query's search is widened by (see Search3Args::widen_max)
@@ -1146,7 +1156,11 @@ __device__ __forceinline__ uint32_t uni32(uint32_t v)
 
 // CERT: check and keep certificates (a pass right after a cold start does neither: its
 // moves outrun any certificate, and the bookkeeping costs registers).
-template <int L, bool CERT>
+// BAIL: batches that walk for too long are given up on (Search3Args::bail_ticks).  A build of
+// its own: the kernel is short of scalar registers, and the few the deadline takes cost
+// every walk 3 % whether or not a batch is ever given up on; the host takes this build for
+// targets whose triangles' sizes range widely, the only ones where it matters.
+template <int L, bool CERT, bool BAIL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_search3w(Search3Args a)
 {
   float* const cert = CERT ? a.cert : nullptr;
@@ -1240,6 +1254,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
 #ifdef ICPX_STATS
     const unsigned long long bt0 = wall_clock64(), bs0 = st_0;
 #endif
+    // (when the batch's walk is to be given up on, by the shader clock counted in units of
+    // 64 cycles; the constant 100 MHz clock takes several times as long to answer)
+    // (0: never; a deadline that comes out as 0 is moved on by a tick)
+    const uint32_t walk_end =
+      (BAIL && a.bail_ticks) ? max((uint32_t)(__builtin_readcyclecounter() >> 6) + a.bail_ticks, 1u) : 0u;
     const int64_t idx = (int64_t)base + lane;
     bool active = idx < total;
     const int64_t q = active ? (a.qlist ? (int64_t)a.qlist[idx] : idx) : 0;
@@ -1696,7 +1715,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
       {
         __builtin_amdgcn_wave_barrier();
         n = uni32(stk[--sp]);
+        // Is the batch to be given up on?  By the clock, not by a count of steps (a step of a
+        // batch in trouble, with its queues full and a round of screens per leaf, takes
+        // several times an ordinary one), looked at when the walk comes back up to a stack
+        // depth that is a multiple of four, and with visits still owed (a walk given up on
+        // leaves the loop with a stack that is not empty: that is how the code below knows).
+        if constexpr (BAIL)
+        {
+          if (walk_end != 0u && (sp & 3) == 0 && sp != 0 &&
+            (int32_t)((uint32_t)(__builtin_readcyclecounter() >> 6) - walk_end) > 0) [[unlikely]]
+            go = false;
+        }
       }
+    }
+    if (BAIL && sp != 0) [[unlikely]]
+    {
+      // (what is queued is left unscreened: the queries start again, from the best so far)
+      const unsigned long long mb = __ballot(active);
+      uint32_t tb = 0u;
+      if (lane == 0)
+        tb = atomicAdd(&a.counters[3], (uint32_t)__popcll(mb));
+      tb = uni32(tb);
+      if (active)
+      {
+        a.hint[q] = cnt >= 1 ? ring[0][lane] : -1;
+        a.bail_list[tb + (uint32_t)__popcll(mb & lt)] = (uint32_t)q;
+      }
+      continue;
     }
     // what is still queued, against the bounds as they stand at the end of the walk
     purge();

@@ -73,10 +73,16 @@ __device__ inline void solve_and_publish(RunState* s, const double* __restrict__
   uint32_t listed_now, uint32_t contested_now, RunRecord* rec, uint32_t seq, float src_rmax = 0.f,
   float anchor_reach = 0.f, uint32_t nq_total = 0u)
 {
-  double Tm[16];
+  double Tm[16], Tc[12];
 #pragma unroll
   for (int i = 0; i < 16; i++)
     Tm[i] = s->T[i];
+  // (the certificates' transform with the rest: read where the anchor test needs it, the read
+  // is a trip to memory behind the solve)
+#pragma unroll
+  for (int i = 0; i < 12; i++)
+    Tc[i] = s->cert_T[i];
+  const int32_t cert_ok = s->cert_ok;
   double mean = s->mean, n = s->n;
   int32_t iters = s->iters, status = s->status, done = s->done;
   uint32_t fallback = s->fallback;
@@ -122,14 +128,14 @@ __device__ inline void solve_and_publish(RunState* s, const double* __restrict__
       {
         for (int k = 0; k < 3; k++)
         {
-          const double dlt = Tn[4 * r + k] - s->cert_T[4 * r + k];
+          const double dlt = Tn[4 * r + k] - Tc[4 * r + k];
           r2 += dlt * dlt;
         }
-        const double dlt = Tn[4 * r + 3] - s->cert_T[4 * r + 3];
+        const double dlt = Tn[4 * r + 3] - Tc[4 * r + 3];
         t2 += dlt * dlt;
       }
       const double reach = (sqrt(r2) * (double)src_rmax + sqrt(t2)) * 1.000001;
-      s->anchored = (s->cert_ok != 0 && anchor_reach > 0.f && reach <= (double)anchor_reach) ? 1 : 0;
+      s->anchored = (cert_ok != 0 && anchor_reach > 0.f && reach <= (double)anchor_reach) ? 1 : 0;
     }
     if (done)
     {

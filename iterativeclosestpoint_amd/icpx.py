@@ -35,7 +35,7 @@ DEV_SYMBOLS = (
     "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local", "icpx_set_refill",
     "icpx_set_finalize", "icpx_set_lean", "icpx_set_anchor", "icpx_set_shard_order",
     "icpx_set_certify_min", "icpx_set_wave_blocks", "icpx_set_query_curve", "icpx_set_noisy_policy", "icpx_set_seed",
-    "icpx_set_weigh",
+    "icpx_set_weigh", "icpx_set_bail",
 )
 
 
@@ -111,6 +111,7 @@ def load():
     lib.icpx_set_leaf_size.argtypes = [vp, ci]
     lib.icpx_set_persistent.argtypes = [vp, ci]
     lib.icpx_set_refill.argtypes = [vp, ci]
+    lib.icpx_set_bail.argtypes = [vp, ci]
     lib.icpx_set_finalize.argtypes = [vp, ci]
     lib.icpx_set_lean.argtypes = [vp, ci]
     lib.icpx_set_anchor.argtypes = [vp, ci]
@@ -195,14 +196,15 @@ class Context:
 
     def debug_stats(self):
         """{shortcut passes, tree-only passes, neighbour-list builds, list radius}."""
-        v = np.zeros(14, np.int64)
-        _chk(load().icpx_debug_dump(self._h, 4, _p(v), 14))
+        v = np.zeros(16, np.int64)
+        _chk(load().icpx_debug_dump(self._h, 4, _p(v), 16))
         return dict(local_passes=int(v[0]), tree_passes=int(v[1]), nbr_builds=int(v[2]),
                     nbr_eps=float(v[3]) * 1e-9, nbr_total=int(v[4]), certify_passes=int(v[5]),
                     split_passes=int(v[6]), split_wave=int(v[7]), split_pool=int(v[8]),
                     winding_flips=int(v[9]), direct_passes=int(v[10]),
                     lean_passes=int(v[11]), lean_failures=int(v[12]),
-                    unorientable=bool(v[13]))
+                    unorientable=bool(v[13]), mesh_grading=float(v[14]) * 1e-3,
+                    bail_passes=int(v[15]))
 
     def debug_counters(self):
         """Counters of the last lane-per-query pass: {ties, overflows, pool position, fallbacks}."""
@@ -248,6 +250,11 @@ class Context:
 
     def set_refill(self, lanes):
         _chk(load().icpx_set_refill(self._h, int(lanes)))
+
+    def set_bail(self, microseconds):
+        """Microseconds after which a whole pass of the wavefront walk gives up on a batch:
+        1 by the cloud's size (default), 0 never, else that many."""
+        _chk(load().icpx_set_bail(self._h, int(microseconds)))
 
     def set_finalize(self, build):
         """0: by size; 1: sums in registers; 2: sums on the matrix core."""

@@ -60,10 +60,14 @@ def apply(M, xyz):
     return (p @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
 
 
-def bumpy_torus(nu, nv, seed=SEED, R=1.0, r=0.4, amp=0.08):
+def bumpy_torus(nu, nv, seed=SEED, R=1.0, r=0.4, amp=0.08, grade=0.0):
     """Closed torus with a smooth seeded radial displacement.
 
     Returns (xyz float32 [nu*nv,3], tri int32 [2*nu*nv,3]); outward orientation.
+    grade in [0, 1): the grid lines are drawn together on one side of the torus and apart on
+    the other in both directions (parameter s -> s + grade sin s), so that edge lengths vary
+    by (1 + grade) / (1 - grade) and the quads' shapes from squares to slivers, as the
+    triangles of a decimated scan do.
     """
     k = 8
     a = u01(seed, 1, k) * (amp / k)
@@ -73,6 +77,9 @@ def bumpy_torus(nu, nv, seed=SEED, R=1.0, r=0.4, amp=0.08):
     ps = u01(seed, 5, k) * 2 * np.pi
     u = (np.arange(nu, dtype=np.float64) * (2 * np.pi / nu))[:, None]
     v = (np.arange(nv, dtype=np.float64) * (2 * np.pi / nv))[None, :]
+    if grade:
+        u = u + grade * np.sin(u)
+        v = v + grade * np.sin(v + 1.0)
     d = np.zeros((nu, nv))
     for i in range(k):
         d += a[i] * np.sin(m[i] * u + ph[i]) * np.sin(n[i] * v + ps[i])
@@ -197,3 +204,16 @@ def config_c5(nu=256, nv=128, npts=40_000, outlier_frac=0.2):
     return dict(name="c5", target_xyz=xyz, target_tri=ttri, source_xyz=src, source_normals=None,
                 metric=1, max_landmarks=len(src), max_dist=0.02 * diag(xyz), max_iter=30,
                 truth=M)
+
+
+def config_c6(nu=1000, nv=500, npts=1_000_000, grade=0.97):
+    """A graded mesh: the torus of c3 with its grid lines drawn together on one side (edge
+    lengths over a range of 65, areas of 4000, squares to slivers), area-uniform samples moved
+    as in c3, point-to-plane."""
+    xyz, tri = bumpy_torus(nu, nv, grade=grade)
+    pts, f, fn = sample_surface(xyz, tri, npts)
+    d = diag(xyz)
+    M = rigid(ry=5.0, t=(0.01 * d / np.sqrt(3),) * 3)
+    src = apply(M, pts)
+    return dict(name="c6", target_xyz=xyz, target_tri=tri, source_xyz=src, source_normals=None,
+                metric=1, max_landmarks=npts, max_dist=10.0, max_iter=50, truth=M)

@@ -318,6 +318,42 @@ def test_midsize_against_grid_oracle(icpx, synth, oracle):
         ctx.close()
 
 
+def test_graded_mesh_and_batches_given_up_on(icpx, synth, oracle):
+    """A target whose triangles' sizes range over a factor of 65 (squares to slivers), the
+    cloud a few dozen of its small edge lengths off: a few batches of the wavefront walk have
+    thousands of boxes within their bounds, and the walk gives up on them (their queries are
+    searched one wavefront each).  Rows equal the oracle's with the library's own choice, with
+    a budget so short that most batches are given up on, and with none; the registrations
+    those three run are the same to the last bit."""
+    c = synth.config_c6(300, 200, 80_000)
+    xyz, tri, src = c["target_xyz"], c["target_tri"], c["source_xyz"]
+    mesh = oracle.Mesh(xyz, tri)
+    ref = mesh.correspond(src, step=1, max_dist=10.0, grid=True)
+    T2 = synth.rigid(rz=0.3)
+    ref2 = mesh.correspond(src, T=T2, step=1, max_dist=10.0, grid=True)
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = 1, 12, len(src), 10.0
+    runs = []
+    for bail in (1, 20, 0):
+        ctx = icpx.Context(0)
+        ctx.set_persistent(3)  # whole passes by the wavefront walk, whatever the density
+        ctx.set_bail(bail)
+        ctx.set_target(xyz, tri)
+        ctx.set_source(src)
+        check_rows(ctx.correspond(np.eye(4), max_dist=10.0), ref)   # cold
+        check_rows(ctx.correspond(T2, max_dist=10.0), ref2)         # hinted, moved
+        st = ctx.debug_stats()
+        assert st["mesh_grading"] > 8.0
+        assert (st["bail_passes"] > 0) == (bail != 0)
+        runs.append(ctx.run(p))
+        ctx.close()
+    for T, it, mean, status in runs[1:]:
+        assert np.array_equal(T, runs[0][0]) and it == runs[0][1] and mean == runs[0][2]
+    # the oracle's own loop from the same start
+    To = mesh.icp(src, metric=1, max_iter=12, max_landmarks=len(src), max_dist=10.0)[0]
+    assert rel_err(runs[0][0], To) < 1e-6
+
+
 def test_vtkicp_surface(icpx, synth, small):
     from iterativeclosestpoint_amd import vtkICP, vtkPolyData
     c, mesh = small
