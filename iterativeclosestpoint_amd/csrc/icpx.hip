@@ -297,6 +297,8 @@ constexpr int PASS_COUNTERS = 16 + CERTIFY_SEGS * CERTIFY_SEG_STRIDE;
 static_assert(XPOOL_FIRST + (XPOOLS - 1) * XPOOL_STRIDE < PASS_COUNTERS && XPOOL_FIRST > 16 &&
     (XPOOL_FIRST - 16) % CERTIFY_SEG_STRIDE != 0 && XPOOL_STRIDE == CERTIFY_SEG_STRIDE,
   "the tree kernels' pool counters lie among the pass counters, beside the list's segment counts");
+static_assert(WALK_DONE < PASS_COUNTERS && (WALK_TIME - 16) % CERTIFY_SEG_STRIDE > 1,
+  "the walk's figures lie beside the first two pool counters");
 
 struct icpx_ctx
 {
@@ -2144,6 +2146,14 @@ static int64_t policy_nq(const icpx_ctx* c)
 // How many queries there are to the mesh's triangles where this rank searches: shards cut
 // from the curve cover one stretch of the surface each at the whole cloud's density, blocks
 // of kept indices are spread over all of it at a fraction.
+// Triangles per point up to which a whole pass goes one walk per wavefront: measured on cold
+// passes, the walk against the pooled lanes, 40 000 / 200 000 points on a million triangles
+// 1.40 / 0.70 against 2.56 / 2.73 ms, a million / 100 000 on ten million 3.9 / 5.1 against
+// 12.5 / 6.9 ms, 40 000 on ten million 6.3 against 7.4 ms (the pooled lanes' cold pass over ten
+// million triangles takes 7 ms however few the queries: one lane's longest walk); sparser
+// still, the 64 queries of a batch share nothing and their walks run one after the other in
+// one wavefront.  (The rule was 4 until it was measured.)
+constexpr int64_t WALK_DENSITY = 256;
 static int64_t density_nq(const icpx_ctx* c)
 {
   return c->curve_shard ? c->nk : policy_nq(c);
@@ -2236,7 +2246,7 @@ static int prepare_local(icpx_ctx* c, bool* use)
     // pass's winners are far from this pass's, and a whole pass of the tree kernel (which
     // re-seeds such queries) is cheaper than a long walk plus the tree for what is left
     c->after_cold = false;
-    if (c->persistent >= 3 && density_nq(c) * 4 >= c->nt)
+    if (c->persistent >= 3 && density_nq(c) * WALK_DENSITY >= c->nt)
       return ICPX_OK;
   }
   if (c->stat_pending && hipEventQuery(c->ev_stat) == hipSuccess)
@@ -2379,7 +2389,7 @@ static int run_search3(icpx_ctx* c)
   // sparse cloud, is scattered and goes one pooled lane per query
   int mode = c->persistent;
   if (mode == 4)
-    mode = (!use_local && density_nq(c) * 4 >= c->nt) ? 3 : 1;
+    mode = (!use_local && density_nq(c) * WALK_DENSITY >= c->nt) ? 3 : 1;
   // the wavefront walk, the pooled lanes and the shortcut keep certificates; the other
   // variants do not, and a pass of theirs leaves the certificates behind
   // (nor does the wavefront walk on a cold pass and the one after it: those moves outrun

@@ -918,6 +918,11 @@ constexpr int XPOOLS = 8;
 constexpr int XPOOL_FIRST = 17;
 constexpr int XPOOL_STRIDE = 64;
 constexpr uint32_t XCHUNK = 128; // consecutive batches (of 64 queries) that belong to one run
+// ... and, in the word after the first two pool counters, what the walk that can give up on a
+// batch knows of the pass so far: the time its finished batches took (units of 256 shader
+// cycles) and their number (zero between passes)
+constexpr int WALK_TIME = XPOOL_FIRST + 1;
+constexpr int WALK_DONE = XPOOL_FIRST + 1 + XPOOL_STRIDE;
 
 // Block partials -> the ICPX_NSUMS totals.  One 64-lane block per sum: lane l adds
 // partials l, l+64, ... in that order, then a fixed xor-shuffle tree; the shape
@@ -1009,6 +1014,8 @@ __device__ __forceinline__ bool reduce_partials_body(
       counters[16 + l * 64] = 0u;
     if (l < XPOOLS)
       counters[XPOOL_FIRST + l * XPOOL_STRIDE] = 0u; // (k_search3w's pool counters)
+    if (l < 2)
+      counters[WALK_TIME + l * XPOOL_STRIDE] = 0u; // (... and its batches' time and number)
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1)
       len += __shfl_xor(len, m, 64);

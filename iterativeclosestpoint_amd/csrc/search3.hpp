@@ -1257,8 +1257,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     // (when the batch's walk is to be given up on, by the shader clock counted in units of
     // 64 cycles; the constant 100 MHz clock takes several times as long to answer)
     // (0: never; a deadline that comes out as 0 is moved on by a tick)
-    const uint32_t walk_end =
-      (BAIL && a.bail_ticks) ? max((uint32_t)(__builtin_readcyclecounter() >> 6) + a.bail_ticks, 1u) : 0u;
+    const uint32_t walk_t0 = BAIL ? (uint32_t)(__builtin_readcyclecounter() >> 6) : 0u;
+    uint32_t walk_end = (BAIL && a.bail_ticks) ? max(walk_t0 + a.bail_ticks, 1u) : 0u;
     const int64_t idx = (int64_t)base + lane;
     bool active = idx < total;
     const int64_t q = active ? (a.qlist ? (int64_t)a.qlist[idx] : idx) : 0;
@@ -1722,9 +1722,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         // leaves the loop with a stack that is not empty: that is how the code below knows).
         if constexpr (BAIL)
         {
-          if (walk_end != 0u && (sp & 3) == 0 && sp != 0 &&
-            (int32_t)((uint32_t)(__builtin_readcyclecounter() >> 6) - walk_end) > 0) [[unlikely]]
-            go = false;
+          if (walk_end != 0u && (sp & 3) == 0 && sp != 0) [[unlikely]]
+          {
+            const uint32_t now = (uint32_t)(__builtin_readcyclecounter() >> 6);
+            if ((int32_t)(now - walk_end) > 0)
+            {
+              // Past the deadline: given up on if the batch has also taken four times what the
+              // pass's finished batches took on average (where every batch is slow, a target of
+              // slivers, none is what the pass waits for); else looked at again a quarter of
+              // its time so far later.
+              uint32_t tsum = 0u, tcnt = 0u;
+              if (lane == 0)
+              {
+                tsum = atomicAdd(&a.counters[WALK_TIME], 0u);
+                tcnt = atomicAdd(&a.counters[WALK_DONE], 0u);
+              }
+              tsum = uni32(tsum);
+              tcnt = uni32(tcnt);
+              const uint32_t spent = now - walk_t0;
+              if (tcnt >= 64u && (uint64_t)(spent >> 2) * tcnt > 4ull * tsum)
+                go = false;
+              else
+                walk_end = max(now + (spent >> 2), 1u);
+            }
+          }
         }
       }
     }
@@ -1742,6 +1763,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         a.bail_list[tb + (uint32_t)__popcll(mb & lt)] = (uint32_t)q;
       }
       continue;
+    }
+    if (BAIL && walk_end != 0u && lane == 0)
+    {
+      // (a finished walk's time goes into the pass's figures)
+      atomicAdd(&a.counters[WALK_TIME], ((uint32_t)(__builtin_readcyclecounter() >> 6) - walk_t0) >> 2);
+      atomicAdd(&a.counters[WALK_DONE], 1u);
     }
     // what is still queued, against the bounds as they stand at the end of the walk
     purge();

@@ -234,9 +234,10 @@ def test_policy_switches_change_nothing(icpx, synth, oracle):
     ref = mesh.correspond(src[pick], T=T0, step=1, max_dist=10.0, grid=True)
     for k in ("cell", "dist", "closest"):
         assert np.array_equal(rows[k][pick], ref[k]), k
-    # the density rule (4 nq >= nt picks the walk per wavefront for whole passes)
+    # the density rule (256 nq >= nt picks the walk per wavefront for whole passes), and a cloud
+    # that was on the other side of it while the rule was 4 nq >= nt
     nt = len(tri)
-    for n in (nt // 4 - 100, nt // 4 + 100):
+    for n in (nt // 256 - 100, nt // 256 + 100, nt // 4 - 100):
         ctx2 = icpx.Context(0)
         ctx2.set_group_width(1)
         ctx2.set_target(xyz, tri)

@@ -1,0 +1,81 @@
+"""Development aid: registrations of shapes the benchmark's workloads do not cover (a far start,
+a sparse and a dense cloud, an elongated scene, heavy noise), pass by pass, to find where the
+host's policy or a kernel falls off a cliff."""
+import os
+import sys
+import time
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401,E402
+from iterativeclosestpoint_amd import icpx, synth  # noqa: E402
+
+
+def case(name):
+    S = synth
+    if name == "far":      # C3's pair from 15 % of the diagonal and 25 degrees off
+        c = S.config_c3()
+        xyz, tri = c["target_xyz"], c["target_tri"]
+        pts, f, fn = S.sample_surface(xyz, tri, 1_000_000)
+        M = S.rigid(ry=25.0, t=(0.15 * S.diag(xyz) / np.sqrt(3),) * 3)
+        c.update(source_xyz=S.apply(M, pts), source_normals=None, metric=1, truth=M)
+    elif name == "sparse":  # 100 000 points on C3's million triangles
+        c = S.config_c3(npts=100_000)
+    elif name.startswith("sparse"):  # sparse<points in thousands>k[x<triangles in millions>m]
+        a, _, b = name[6:].partition("x")
+        nu, nv = (2500, 2000) if b == "10m" else (1000, 500)
+        c = S.config_c3(nu=nu, nv=nv, npts=1000 * int(a.rstrip("k")))
+    elif name == "dense":   # 4 million points on 20 000 triangles
+        c = S.config_c3(nu=100, nv=100, npts=4_000_000)
+    elif name == "long":    # C3's scene stretched twentyfold along x
+        c = S.config_c3()
+        sc = np.array([20.0, 1.0, 1.0])
+        xyz = (c["target_xyz"].astype(np.float64) * sc).astype(np.float32)
+        pts, f, fn = S.sample_surface(xyz, c["target_tri"], 1_000_000)
+        M = S.rigid(ry=1.0, t=(0.01 * S.diag(xyz) / np.sqrt(3),) * 3)
+        c.update(target_xyz=xyz, source_xyz=S.apply(M, pts), source_normals=None, metric=1, truth=M)
+    elif name == "noisy":   # C3's pair with noise of five edge lengths
+        c = S.config_c3()
+        xyz, tri = c["target_xyz"], c["target_tri"]
+        pts, f, fn = S.sample_surface(xyz, tri, 1_000_000)
+        noise = np.stack([S.gaussian(S.SEED, 32 + 2 * k, len(pts)) for k in range(3)], -1) * 0.03
+        c.update(source_xyz=S.apply(c["truth"], pts.astype(np.float64) + noise), source_normals=None, metric=1)
+    elif name == "c3":
+        c = S.config_c3()
+    elif name == "c6":      # the graded torus
+        c = S.config_c6()
+    else:
+        raise SystemExit("unknown case " + name)
+    return c
+
+
+for spec in (sys.argv[1:] or ["c3", "far", "sparse", "dense", "long", "noisy"]):
+    # name[:knob=value,...] with the knobs of icpx.Context (persistent, bail, local, ...)
+    name, _, knobs = spec.partition(":")
+    c = case(name)
+    ctx = icpx.Context(0)
+    for kv in filter(None, knobs.split(",")):
+        k, v = kv.split("=")
+        getattr(ctx, "set_" + k)(int(v))
+    ctx.set_target(c["target_xyz"], c["target_tri"])
+    ctx.set_source(c["source_xyz"], c["source_normals"])
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = c["metric"], 50, len(c["source_xyz"]), c["max_dist"]
+    ctx.run(p)
+    t = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        T, it, mean, st = ctx.run(p)
+        t.append(1e3 * (time.perf_counter() - t0))
+    ctx.set_timing(2)
+    ctx.run(p)
+    ms, kind, hinted = ctx.get_pass_timings()
+    ctx.set_timing(0)
+    stt = ctx.debug_stats()
+    print("%-20s %d tri %d pts: registration %.2f ms (%d iterations, status %d, mean %.2e, off truth %.1e)" %
+          (spec, len(c["target_tri"]), len(c["source_xyz"]), np.median(t), it, st, mean,
+           np.abs(T @ c["truth"] - np.eye(4)).max()))
+    print("        passes ms", [round(float(v), 3) for v in ms[:10]], "... settled %.3f" % float(np.median(ms[25:])),
+          "kinds", [int(k) for k in kind[:10]])
+    print("        ", {k: v for k, v in stt.items() if v})
+    ctx.close()
