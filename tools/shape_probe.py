@@ -40,6 +40,14 @@ def case(name):
         pts, f, fn = S.sample_surface(xyz, tri, 1_000_000)
         noise = np.stack([S.gaussian(S.SEED, 32 + 2 * k, len(pts)) for k in range(3)], -1) * 0.03
         c.update(source_xyz=S.apply(c["truth"], pts.astype(np.float64) + noise), source_normals=None, metric=1)
+    elif name == "cube":    # a million points on the twelve triangles of a cube
+        v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float32)
+        t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5],
+                      [2, 3, 7], [2, 7, 6], [3, 0, 4], [3, 4, 7]], np.int32)
+        pts, f, fn = S.sample_surface(v, t, 1_000_000)
+        M = S.rigid(ry=3.0, t=(0.01, 0.02, 0.015))
+        c = dict(target_xyz=v, target_tri=t, source_xyz=S.apply(M, pts), source_normals=None, metric=1,
+                 max_dist=10.0, truth=M)
     elif name == "c3":
         c = S.config_c3()
     elif name == "c6":      # the graded torus
