@@ -91,7 +91,7 @@ def measured_traffic(workload):
     out = {}
     for k, v in t.items():
         flat = k.replace(" ", "")
-        key = "k_search3w_cold" if flat.startswith("k_search3w<4,false>") else \
+        key = "k_search3w_cold" if flat.startswith("k_search3w<4,false") else \
             "k_finalize_mx_lean" if (flat.startswith("k_finalize_mx") and flat.endswith("true>")) else None
         if key and key not in out:
             out[key] = {"fetch_max": v["fetch_bytes_max_x2"], "fetch_mean": v["fetch_bytes_mean_x2"],
