@@ -52,6 +52,16 @@ def case(name):
         c = S.config_c3()
     elif name == "c6":      # the graded torus
         c = S.config_c6()
+    elif name == "c6noisy":  # ... with noise of two mean edge lengths (many small ones)
+        c = S.config_c6()
+        pts, f, fn = S.sample_surface(c["target_xyz"], c["target_tri"], 1_000_000)
+        noise = np.stack([S.gaussian(S.SEED, 32 + 2 * k, len(pts)) for k in range(3)], -1) * 0.012
+        c.update(source_xyz=S.apply(c["truth"], pts.astype(np.float64) + noise))
+    elif name == "c6big":    # ten million graded triangles, sixteen million noisy points
+        c = S.config_c6(nu=2500, nv=2000, npts=16_000_000)
+        pts, f, fn = S.sample_surface(c["target_xyz"], c["target_tri"], 16_000_000)
+        noise = np.stack([S.gaussian(S.SEED, 32 + 2 * k, len(pts)) for k in range(3)], -1) * (1e-3 * S.diag(c["target_xyz"]))
+        c.update(source_xyz=S.apply(c["truth"], pts.astype(np.float64) + noise))
     else:
         raise SystemExit("unknown case " + name)
     return c
