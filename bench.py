@@ -18,6 +18,8 @@ rotY 5 deg + 1 % of the diagonal, symmetric (plane-to-plane) metric, every point
 c4: 10,000,000 triangles against 16,000,000 noisy samples, point-to-plane (the north star's
 target run).  The default one-GPU run measures c3 (the top-level figures) and then c4 with 1
 warm-up + 3 registrations, reported under config.c4 with its own roofline figures.
+c5big: partial overlap with 20 % outliers at c3's size; c6: c3's size on a graded mesh (edge
+lengths over a range of 65, squares to slivers), point-to-plane.
 Scaling.  weak (default): every rank holds its own scan of the replicated surface.
 strong (--scaling strong; what config 4 asks for): every rank loads the SAME cloud and
 searches its share of it (icpx_set_shard); rank 0 then repeats the registration alone on the

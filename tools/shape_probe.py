@@ -40,6 +40,10 @@ def case(name):
         pts, f, fn = S.sample_surface(xyz, tri, 1_000_000)
         noise = np.stack([S.gaussian(S.SEED, 32 + 2 * k, len(pts)) for k in range(3)], -1) * 0.03
         c.update(source_xyz=S.apply(c["truth"], pts.astype(np.float64) + noise), source_normals=None, metric=1)
+    elif name == "c4clean":  # C4's pair without the noise: every foot point inside a triangle
+        c = S.config_c4()
+        pts, f, fn = S.sample_surface(c["target_xyz"], c["target_tri"], 16_000_000)
+        c.update(source_xyz=S.apply(c["truth"], pts))
     elif name == "cube":    # a million points on the twelve triangles of a cube
         v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float32)
         t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5],
