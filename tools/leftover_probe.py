@@ -12,7 +12,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="c5big")
 ap.add_argument("--shard", default="0/1")
 a = ap.parse_args()
-c = {"c3": synth.config_c3, "c4": synth.config_c4,
+def c6noisy():
+    """The graded torus under a cloud with noise of two mean edge lengths."""
+    c = synth.config_c6()
+    pts, f, fn = synth.sample_surface(c["target_xyz"], c["target_tri"], 1_000_000)
+    noise = np.stack([synth.gaussian(synth.SEED, 32 + 2 * k, len(pts)) for k in range(3)], -1) * 0.012
+    c.update(source_xyz=synth.apply(c["truth"], pts.astype(np.float64) + noise))
+    return c
+
+
+c = {"c3": synth.config_c3, "c4": synth.config_c4, "c6": synth.config_c6, "c6noisy": c6noisy,
      "c5big": lambda: synth.config_c5(nu=1000, nv=500, npts=1_200_000)}[a.workload]()
 r, w = (int(v) for v in a.shard.split("/"))
 ctx = icpx.Context(0)
