@@ -996,6 +996,45 @@ def test_certificates_change_nothing(icpx, synth, oracle):
     assert min(kept[2:8]) > 0.9 and kept[-1] > 0.9  # most queries hold a certificate
 
 
+def test_certified_sets_of_exact_ties_weighed_by_k_contested(icpx, synth, small):
+    """Points that sit exactly on the mesh's vertices and on midpoints of its edges tie between
+    two to eight triangles for good: they stand on set certificates, and every settled pass
+    weighs their sets again, dozens of them in every 512 consecutive queries (the path of
+    k_contested that lists the marked queries and deals them out a lane apiece, where cell
+    ids are read only when two squared distances are equal).  Rows equal the oracle's in every
+    pass, whoever weighs (k_contested, the finalize, with and without leads)."""
+    c, mesh = small
+    xyz, tri = c["target_xyz"], c["target_tri"]
+    e = np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]])
+    mid = (0.5 * (xyz[e[:, 0]].astype(np.float64) + xyz[e[:, 1]])).astype(np.float32)
+    pts, f, fn = synth.sample_surface(xyz, tri, 4000, seed=9)
+    src = np.concatenate([xyz, mid[::3], pts])
+    moves = [0, 0, 0, 1e-9, 1e-9, 3e-9, 0, 1e-8]
+    base = None
+    for weigh in (0, 1, 2, 3):
+        ctx = icpx.Context(0)
+        ctx.set_group_width(1)
+        ctx.set_weigh(weigh)
+        ctx.set_target(xyz, tri)
+        ctx.set_source(src)
+        T = np.eye(4)
+        out = []
+        for i, m in enumerate(moves):
+            T = synth.rigid(rz=10 * m, t=(m, 0, -m)) @ T
+            rows = ctx.correspond(T, step=1, max_dist=10.0)
+            if weigh == 0 and i in (0, 2, 5, 7):
+                check_rows(rows, mesh.correspond(src, T=T, step=1, max_dist=10.0, grid=True))
+            out.append((rows, ctx.accumulate(1, T, step=1, max_dist=10.0)))
+        bits = ctx.debug_certificates(len(src)).view(np.uint32)
+        assert ((bits & 1) == 1).sum() > len(src) // 8   # the tied points stand on sets
+        ctx.close()
+        if base is None:
+            base = out
+        for (r, s_), (r0, s0) in zip(out, base):
+            check_rows(r, r0)
+            assert np.array_equal(s_, s0)
+
+
 def _point_triangle_dist(q, P):
     """Distances from points q (n,3) to triangles P (m,3,3), all pairs, float64 (Ericson)."""
     a, b, c = P[None, :, 0], P[None, :, 1], P[None, :, 2]
