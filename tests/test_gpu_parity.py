@@ -1035,6 +1035,52 @@ def test_certified_sets_of_exact_ties_weighed_by_k_contested(icpx, synth, small)
             assert np.array_equal(s_, s0)
 
 
+def test_scene_far_from_the_origin(icpx, synth, oracle):
+    """Coordinates four hundred times the scene's extent: every rounding allowance is four
+    hundred times what it is about the origin, the neighbour lists are not worth building, and a cloud of
+    300 000 points is then served by the certificates' own kernel and the tree kernels.  Rows
+    are the oracle's, cold, hinted and after moves; the registration is the oracle's loop's."""
+    xyz, tri = synth.bumpy_torus(160, 80)
+    shift = np.array([1000.0, -500.0, 250.0])
+    xyz = (xyz.astype(np.float64) + shift).astype(np.float32)
+    pts, f, fn = synth.sample_surface(xyz, tri, 300_000, seed=13)
+    ctr = 0.5 * (xyz.max(0).astype(np.float64) + xyz.min(0))
+    R = synth.rigid(ry=2.0, t=(0.01, -0.005, 0.008))
+    M = np.eye(4)
+    M[:3, :3] = R[:3, :3]
+    M[:3, 3] = R[:3, 3] + ctr - R[:3, :3] @ ctr
+    src = synth.apply(M, pts)
+    mesh = oracle.Mesh(xyz, tri)
+    ctx = icpx.Context(0)
+    ctx.set_target(xyz, tri)
+    ctx.set_source(src)
+    T = np.eye(4)
+    for m in (0, 0, 1e-4, 1e-2, 1e-4, 1e-4):
+        T = synth.rigid(t=(m, -m, 0.5 * m)) @ T
+        got = ctx.correspond(T, step=1, max_dist=10.0)
+        pick = np.arange(0, len(src), 7)
+        ref = mesh.correspond(src[pick], T=T, step=1, max_dist=10.0, grid=True)
+        for k in ("cell", "dist", "closest"):
+            assert np.array_equal(got[k][pick], ref[k]), (m, k)
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = 1, 20, len(src), 10.0
+    Tg, it, mean, st = ctx.run(p)
+    stats = ctx.debug_stats()
+    assert stats["nbr_eps"] == 0.0 and stats["direct_passes"] > 0, stats
+    To = mesh.icp(src, metric=1, max_iter=20, max_landmarks=len(src), max_dist=10.0)[0]
+    # (a rotation that differs in its eighth digit moves a point a thousand units from the
+    # origin by a float's last bit, which is what the rows are rounded to: the two loops agree
+    # in where they put the cloud, to 1e-6 of the coordinates' size, not in the 4x4's entries)
+    p64 = src.astype(np.float64)
+    where_g = p64 @ Tg[:3, :3].T + Tg[:3, 3]
+    where_o = p64 @ To[:3, :3].T + To[:3, 3]
+    gap = float(np.abs(where_g - where_o).max() / np.abs(p64).max())
+    print("scene far from the origin: the loops' clouds differ by %.2e of the coordinates' size" % gap)
+    assert gap < 1e-6
+    assert np.abs(where_g - pts.astype(np.float64)).max() < 2e-3   # ... and it registers
+    ctx.close()
+
+
 def _point_triangle_dist(q, P):
     """Distances from points q (n,3) to triangles P (m,3,3), all pairs, float64 (Ericson)."""
     a, b, c = P[None, :, 0], P[None, :, 1], P[None, :, 2]

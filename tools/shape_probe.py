@@ -44,6 +44,17 @@ def case(name):
         c = S.config_c4()
         pts, f, fn = S.sample_surface(c["target_xyz"], c["target_tri"], 16_000_000)
         c.update(source_xyz=S.apply(c["truth"], pts))
+    elif name.startswith("offset"):  # C3's scene moved away from the origin by offset<distance>
+        c = S.config_c3()
+        sh = np.array([float(name[6:]), 0.0, 0.0])
+        xyz = (c["target_xyz"].astype(np.float64) + sh).astype(np.float32)
+        pts, f, fn = S.sample_surface(xyz, c["target_tri"], 1_000_000)
+        ctr = 0.5 * (xyz.max(0).astype(np.float64) + xyz.min(0))
+        M0 = S.rigid(ry=5.0, t=(0.01 * S.diag(xyz) / np.sqrt(3),) * 3)
+        M = np.eye(4)
+        M[:3, :3] = M0[:3, :3]
+        M[:3, 3] = M0[:3, 3] + ctr - M0[:3, :3] @ ctr   # (the same motion about the scene's centre)
+        c.update(target_xyz=xyz, source_xyz=S.apply(M, pts), source_normals=None, metric=1, truth=M)
     elif name == "cube":    # a million points on the twelve triangles of a cube
         v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float32)
         t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5],
