@@ -62,8 +62,8 @@ extern "C"
    * queries is given up on and its queries are searched one wavefront each instead (a few
    * queries beside a patch of triangles much smaller than their distance from it keep their
    * whole batch walking for as long as the rest of the pass takes).  1 (default) = on targets
-   * whose triangles' sizes range widely (median longest edge over 2nd percentile of the
-   * shortest above 8), a time that goes by the cloud's size (800 us at least); 0 = never; any
+   * whose triangles' sizes range widely (median longest edge over the shortest edge of
+   * the smallest thousandth above 8), a time that goes by the cloud's size (800 us at least); 0 = never; any
    * other value = on every target, that many.  Same results. */
   int icpx_set_bail(icpx_ctx* ctx, int microseconds);
 

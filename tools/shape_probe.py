@@ -11,6 +11,36 @@ import torch  # noqa: F401,E402
 from iterativeclosestpoint_amd import icpx, synth  # noqa: E402
 
 
+def refine(xyz, tri, sel, m):
+    """Triangles `sel` cut into m x m coplanar ones each (the surface stays what it was)."""
+    P = xyz.astype(np.float64)
+    newv, newt = [], []
+    base = len(xyz)
+    idx = {}
+    k = 0
+    for i in range(m + 1):
+        for j in range(m + 1 - i):
+            idx[(i, j)] = k
+            k += 1
+    per = k
+    ij = np.array(sorted(idx, key=idx.get), np.float64) / m
+    cells = []
+    for i in range(m):
+        for j in range(m - i):
+            cells.append((idx[(i, j)], idx[(i + 1, j)], idx[(i, j + 1)]))
+            if i + j < m - 1:
+                cells.append((idx[(i + 1, j)], idx[(i + 1, j + 1)], idx[(i, j + 1)]))
+    cells = np.array(cells, np.int64)
+    for n, t in enumerate(sel):
+        a, b, c = P[tri[t, 0]], P[tri[t, 1]], P[tri[t, 2]]
+        newv.append(a + ij[:, :1] * (b - a) + ij[:, 1:] * (c - a))
+        newt.append(cells + base + n * per)
+    keep = np.ones(len(tri), bool)
+    keep[sel] = False
+    return (np.concatenate([xyz, np.concatenate(newv).astype(np.float32)]),
+            np.concatenate([tri[keep], np.concatenate(newt).astype(np.int32)]))
+
+
 def case(name):
     S = synth
     if name == "far":      # C3's pair from 15 % of the diagonal and 25 degrees off
@@ -55,6 +85,14 @@ def case(name):
         M[:3, :3] = M0[:3, :3]
         M[:3, 3] = M0[:3, 3] + ctr - M0[:3, :3] @ ctr   # (the same motion about the scene's centre)
         c.update(target_xyz=xyz, source_xyz=S.apply(M, pts), source_normals=None, metric=1, truth=M)
+    elif name.startswith("patch"):  # C3's torus with patch<n> of its triangles cut into 64 x 64 each
+        c = S.config_c3()
+        xyz, tri = c["target_xyz"], c["target_tri"]
+        n = int(name[5:] or 3)
+        cen = xyz[tri].mean(1)
+        sel = np.argsort(np.linalg.norm(cen - cen[12345], axis=1))[:n]
+        xyz2, tri2 = refine(xyz, tri, sel, 64)
+        c.update(target_xyz=xyz2, target_tri=tri2, source_normals=None, metric=1)
     elif name == "cube":    # a million points on the twelve triangles of a cube
         v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float32)
         t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5],
