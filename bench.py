@@ -17,7 +17,8 @@ Workloads.  c3 (default, the configuration the headline metric names): the synth
 rotY 5 deg + 1 % of the diagonal, symmetric (plane-to-plane) metric, every point used.
 c4: 10,000,000 triangles against 16,000,000 noisy samples, point-to-plane (the north star's
 target run).  The default one-GPU run measures c3 (the top-level figures) and then c4 with 1
-warm-up + 3 registrations, reported under config.c4 with its own roofline figures.
+warm-up + 3 registrations, reported under config.c4 with its own roofline figures, and c6
+briefly (config.c6).
 c5big: partial overlap with 20 % outliers at c3's size; c6: c3's size on a graded mesh (edge
 lengths over a range of 65, squares to slivers), point-to-plane.
 Scaling.  weak (default): every rank holds its own scan of the replicated surface.
@@ -481,6 +482,19 @@ def main():
             del c4data
         except Exception as exc:  # (the headline figures above stand whatever happens here)
             c4 = {"error": repr(exc)}
+    # ... and a target the benchmark's tori are not: a million triangles whose edge lengths
+    # range over a factor of 65 (the walk's batches given up on), briefly
+    c6 = None
+    if not args.workload and not args.no_c4 and world == 1 and not emu and not args.force_collective:
+        try:
+            r6, c6data = run_workload(args, "c6", 5, 1, False, None, rank, world, local, collective, modules)
+            c6 = {"value": r6["value"], "unit": "correspondences/s", "ms_per_step": r6["ms_per_step"],
+                  "steps": r6["steps"], "warmup": r6["warmup"], "workload": r6["config"]["workload"],
+                  "registration_ms_median": r6["config"]["registration_ms_median"],
+                  "cold_pass_ms": r6["roofline"].get("kernel_ms"), "passes": r6["config"]["passes"]}
+            del c6data
+        except Exception as exc:
+            c6 = {"error": repr(exc)}
 
     if rank == 0:
         out = {
@@ -501,6 +515,8 @@ def main():
         }
         if c4 is not None:
             out["config"]["c4"] = c4
+        if c6 is not None:
+            out["config"]["c6"] = c6
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(c)
         sys.stdout.flush()
