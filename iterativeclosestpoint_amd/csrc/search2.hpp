@@ -420,9 +420,9 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
   int32_t first_win = -1;
   bool again = false;
 #pragma unroll 1
-  for (int attempt = 0; attempt < (G == 64 ? 2 : 1); attempt++)
+  for (int attempt = 0; attempt < (G == 64 ? 3 : 1); attempt++)
   {
-  if (attempt == 1)
+  if (attempt >= 1)
   {
     if (!again)
       break;
@@ -452,10 +452,12 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
     const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
     eabs = smax * 2.3841858e-07f * 1.0000002f; // 2^-22 of the largest coordinate, rounded up
     tau = 1e-9 * (double)smax;
-    ring_tol = attempt == 0 ? tau : fmax(tau, 64.0 * (double)eabs);
+    // (a third walk, after a second one that met more triangles within its tolerance than the
+    // ring holds: eight allowances)
+    ring_tol = attempt == 0 ? tau : fmax(tau, (attempt == 1 ? 64.0 : 8.0) * (double)eabs);
     if (a.cap2 < 1e300)
       set_best(a.cap2);
-    if (a.use_hint || attempt == 1)
+    if (a.use_hint || attempt >= 1)
     {
       const int32_t hs = attempt == 0 ? a.hint[q] : first_win;
       if (hs >= 0 && a.tid[hs] >= 0)
@@ -621,6 +623,45 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
         }
       }
     }
+    if constexpr (G == 64)
+    {
+      // The second walk ended with more triangles within its tolerance than a set holds (a
+      // point dozens of triangle widths off a patch of small triangles has some forty within
+      // 64 rounding allowances of the nearest): the eight nearest of them are the set, and
+      // what certifies it is the distance of the ninth (screened like the others, to the last
+      // digits of a double: no rounding allowance comes into it), of the nearest triangle
+      // screened and turned away, and of the nearest box turned away.  Without this such a
+      // point has no certificate and is searched, thousands of boxes, on every pass.
+      if (attempt >= 1 && a.cert && a.cand && !flushed && cnt > RING3 && cnt <= Cfg::RING)
+      {
+        double dj = INFINITY;
+        int32_t sj = -1;
+        if (j < cnt)
+        {
+          sj = ring[g][j];
+          d3 P0, P1, P2;
+          load_tri(a.tverts, sj, P0, P1, P2);
+          dj = tri_d2_screen(x, P0, P1, P2);
+        }
+        int rank = 0;
+#pragma unroll 1
+        for (int k = 0; k < cnt; k++)
+        {
+          const double dk = __shfl(dj, k, 64);
+          rank += (dk < dj || (dk == dj && k < j)) ? 1 : 0;
+        }
+        const bool member = j < cnt && rank < RING3;
+        const double d9 = group_min<G>((j < cnt && !member) ? dj : (double)INFINITY);
+        const float m1 = (float)group_min<G>((double)lose1);
+        const float mb = (float)group_min<G>((double)minbox);
+        const float dbox = __builtin_amdgcn_sqrtf(mb) * 0.999999f;
+        nearc = make_certificate(RING3, best, fminf(m1, __double2float_rd(d9) * 0.999999f), INFINITY,
+          dbox, tau, eabs, a.cap2);
+        have_near = true;
+        if (nearc != 0.f && nearc > first_cert && member)
+          a.cand[q * RING3 + rank] = sj;
+      }
+    }
     int32_t win;
     if (cnt == 1 && !flushed)
       win = ring[g][0]; // a single contender needs no exact evaluation here
@@ -641,11 +682,13 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
         fminf(eabs, 0.2f * eabs * eabs / fmaxf(capd, 1e-30f));
       far = (c > 0.f && c < 1e30f) ? -c : 0.f;
     }
-    if (attempt == 1)
+    if (attempt >= 1)
     {
       // (the winner is the first walk's: the exact minimum of a superset of its contenders)
       if (j == 0 && have_near && nearc > first_cert && win == first_win)
         a.cert[q] = cert_rebase_at(nearc, a.cert_ok, a.cert_T, x, a.qpos + 3 * q);
+      // (more triangles within 64 allowances than the ring holds: once more, with eight)
+      again = attempt == 1 && flushed && a.cert && a.cand;
     }
     else
     {

@@ -1266,6 +1266,65 @@ def test_certificate_is_below_the_true_gap(icpx, synth, local):
     assert nled > 0 or local == 1           # (pairs with a clear winner: kept where sets of two are)
 
 
+def test_certificates_of_points_far_above_small_triangles(icpx, synth, oracle):
+    """A noisy cloud over a graded mesh: a point dozens of triangle widths above the small
+    triangles has dozens of them within a hair of the nearest.  Such a point is certified by
+    its eight nearest triangles and the exact distance of the ninth; every certificate,
+    these included, is held against the brute-force gap to the nearest triangle outside the
+    set, rows are the oracle's before and after a small move, and the settled passes leave
+    next to nothing to search."""
+    xyz, tri = synth.bumpy_torus(240, 120, grade=0.985)
+    # (as many points over a small triangle as over a large one: an area-uniform sample of this
+    # size has next to none over the small ones)
+    f = np.minimum((synth.u01(41, 1, 30_000) * len(tri)).astype(np.int64), len(tri) - 1)
+    w = np.sort(np.stack([synth.u01(41, 2, len(f)), synth.u01(41, 3, len(f))], -1), axis=1)
+    bary = np.stack([w[:, 0], w[:, 1] - w[:, 0], 1.0 - w[:, 1]], -1)
+    pts = (xyz[tri[f]].astype(np.float64) * bary[:, :, None]).sum(1)
+    noise = np.stack([synth.gaussian(9, 90 + 2 * k, len(pts)) for k in range(3)], -1) * 0.03
+    src = (pts.astype(np.float64) + noise).astype(np.float32)
+    mesh = oracle.Mesh(xyz, tri)
+    ctx = icpx.Context(0)
+    ctx.set_group_width(1)
+    ctx.set_certify_min(1000)   # served as a cloud of millions: certificates by their own kernel
+    ctx.set_target(xyz, tri)
+    ctx.set_source(src)
+    T = synth.rigid(rz=0.01, t=(1e-4, 0, 0))
+    for _ in range(5):
+        ctx.accumulate(1, T, step=1, max_dist=10.0)
+    T2 = synth.rigid(rx=2e-8, t=(0, 1e-9, 0)) @ T
+    rows = ctx.correspond(T2, step=1, max_dist=10.0)
+    check_rows(rows, mesh.correspond(src, T=T2, step=1, max_dist=10.0, grid=True))
+    left = ctx.debug_counters()["fallback"]
+    cert = ctx.debug_certificates(len(src))
+    order = ctx.debug_query_order(len(src))
+    sets = ctx.debug_contender_sets(len(src))
+    cell = ctx.debug_cell_ids(len(tri))
+    isset = (cert > 0) & ((cert.view(np.uint32) & 1) == 1)
+    size = np.where((sets < 0).any(1), np.argmax(sets < 0, 1), 8)
+    full = np.nonzero(isset & (size == 8))[0]
+    assert len(full) >= 5, "no point stands on a set of eight"
+    assert (cert > 0).mean() > 0.98 and left < len(src) // 200, (float((cert > 0).mean()), left)
+    P = xyz[tri].astype(np.float64)
+    x = src.astype(np.float64) @ T2[:3, :3].T + T2[:3, 3]
+    pick = np.concatenate([full[:300], np.nonzero(isset)[0][:200], np.arange(0, len(src), 97)])
+    for k0 in range(0, len(pick), 250):
+        pos = pick[k0:k0 + 250]
+        dall = _point_triangle_dist(x[order[pos]], P)
+        d = np.sort(dall, axis=1)
+        gap = d[:, 1] - d[:, 0]
+        for i in np.nonzero(isset[pos])[0]:
+            members = sets[pos[i]]
+            members = members[:np.argmax(members < 0)] if (members < 0).any() else members
+            out = np.ones(len(P), bool)
+            out[cell[members]] = False
+            gap[i] = dall[i][out].min() - d[i, 0]
+            # (the nearest triangle is a member: the winner is found among them)
+            assert dall[i][cell[members]].min() == d[i, 0]
+        c = cert[pos]
+        assert np.all(c[c > 0] <= gap[c > 0] + 1e-12), "a certificate exceeds the true gap"
+    ctx.close()
+
+
 def test_tree_and_far_certificates_are_sound(icpx, synth, oracle):
     """Certificates made by the tree kernels, for a cloud that is mostly off the surface and
     partly beyond the distance threshold: a positive one never exceeds the brute-force gap
