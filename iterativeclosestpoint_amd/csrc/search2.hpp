@@ -356,6 +356,7 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
   double ed2 = INFINITY;
   int32_t eid = 0x7fffffff, es = -1;
   bool flushed = false;
+  bool overflowed = false; // the ring had to be resolved early: more contenders than it holds
   int32_t hs_used = -1; // the hinted triangle already sits in the ring
   int top = 0;
   float minlb = INFINITY; // smallest lower bound (squared) of anything this lane turned away
@@ -420,7 +421,7 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
   int32_t first_win = -1;
   bool again = false;
 #pragma unroll 1
-  for (int attempt = 0; attempt < (G == 64 ? 3 : 1); attempt++)
+  for (int attempt = 0; attempt < (G == 64 ? 4 : 1); attempt++)
   {
   if (attempt >= 1)
   {
@@ -435,6 +436,7 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
     eid = 0x7fffffff;
     es = -1;
     flushed = false;
+    overflowed = false;
     hs_used = -1;
     top = 0;
     minlb = INFINITY;
@@ -452,9 +454,9 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
     const float smax = fmaxf(fmaxf(a.scene_max, fabsf(xf)), fmaxf(fabsf(yf), fabsf(zf)));
     eabs = smax * 2.3841858e-07f * 1.0000002f; // 2^-22 of the largest coordinate, rounded up
     tau = 1e-9 * (double)smax;
-    // (a third walk, after a second one that met more triangles within its tolerance than the
-    // ring holds: eight allowances)
-    ring_tol = attempt == 0 ? tau : fmax(tau, (attempt == 1 ? 64.0 : 8.0) * (double)eabs);
+    // (a third and a fourth walk, each after one that met more triangles within its tolerance
+    // than the ring holds: eight allowances, then one)
+    ring_tol = attempt == 0 ? tau : fmax(tau, (attempt == 1 ? 64.0 : attempt == 2 ? 8.0 : 1.0) * (double)eabs);
     if (a.cap2 < 1e300)
       set_best(a.cap2);
     if (a.use_hint || attempt >= 1)
@@ -572,6 +574,7 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
       {
         __builtin_amdgcn_wave_barrier();
         resolve(); // more ties than the ring holds: settle what is there exactly
+        overflowed = true;
       }
       const int r = (G == 64) ? __popcll(bal & ((1ull << j) - 1ull))
                               : __popc(gm & ((1u << j) - 1u));
@@ -687,8 +690,8 @@ __device__ __forceinline__ void search2_body(const Search2Args& a, const Xf& T, 
       // (the winner is the first walk's: the exact minimum of a superset of its contenders)
       if (j == 0 && have_near && nearc > first_cert && win == first_win)
         a.cert[q] = cert_rebase_at(nearc, a.cert_ok, a.cert_T, x, a.qpos + 3 * q);
-      // (more triangles within 64 allowances than the ring holds: once more, with eight)
-      again = attempt == 1 && flushed && a.cert && a.cand;
+      // (more triangles within the tolerance than the ring holds: once more, with an eighth of it)
+      again = attempt < 3 && overflowed && a.cert && a.cand;
     }
     else
     {

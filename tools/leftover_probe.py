@@ -21,7 +21,16 @@ def c6noisy():
     return c
 
 
-c = {"c3": synth.config_c3, "c4": synth.config_c4, "c6": synth.config_c6, "c6noisy": c6noisy,
+def c6big():
+    """Ten million graded triangles under sixteen million noisy points."""
+    c = synth.config_c6(nu=2500, nv=2000, npts=16_000_000)
+    pts, f, fn = synth.sample_surface(c["target_xyz"], c["target_tri"], 16_000_000)
+    noise = np.stack([synth.gaussian(synth.SEED, 32 + 2 * k, len(pts)) for k in range(3)], -1) * (1e-3 * synth.diag(c["target_xyz"]))
+    c.update(source_xyz=synth.apply(c["truth"], pts.astype(np.float64) + noise))
+    return c
+
+
+c = {"c3": synth.config_c3, "c4": synth.config_c4, "c6": synth.config_c6, "c6noisy": c6noisy, "c6big": c6big,
      "c5big": lambda: synth.config_c5(nu=1000, nv=500, npts=1_200_000)}[a.workload]()
 r, w = (int(v) for v in a.shard.split("/"))
 ctx = icpx.Context(0)
