@@ -64,7 +64,8 @@ extern "C"
    * whole batch walking for as long as the rest of the pass takes).  1 (default) = on targets
    * whose triangles' sizes range widely (median longest edge over the shortest edge of
    * the smallest thousandth above 8), a time that goes by the cloud's size (800 us at least); 0 = never; any
-   * other value = on every target, that many.  Same results. */
+   * other value = on every target, that many, and whatever the other batches of the pass took
+   * (by default a batch must also have taken four times their mean).  Same results. */
   int icpx_set_bail(icpx_ctx* ctx, int microseconds);
 
   /* The fused finalize: 0 (default) = by the size of the cloud; 1 = the build that keeps the

@@ -239,6 +239,15 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
     anchor_reach);
 }
 
+// The pools the tree kernels draw their work from, back at their start: for a second such
+// kernel in one pass (the one that serves the queries a walk gave up on; the pass's reduction
+// leaves them at zero for the next pass).
+__global__ void k_reset_pools(uint32_t* __restrict__ counters)
+{
+  if (threadIdx.x < XPOOLS)
+    counters[XPOOL_FIRST + threadIdx.x * XPOOL_STRIDE] = 0u;
+}
+
 // ---- icpx_accumulate_static: scratch that lives in the code object, not on the heap ----
 // Everything that entry point needs beyond the context's meshes and the caller's output: the
 // query order (keys, values, sort histograms), the ordered queries and the block partials.
@@ -371,6 +380,7 @@ struct icpx_ctx
   float4* d_edges = nullptr; // edge half-spaces of the triangles
   QuantGrid qgrid;
   uint32_t* d_fallback = nullptr;
+  uint32_t* d_bail = nullptr; // queries of the batches a walk gave up on (count in counters[2])
   double* h_stat = nullptr; // pinned {n, sum |s-t|, shortcut fallbacks} of a finished pass
   hipEvent_t ev_stat = nullptr;
   bool stat_pending = false, stat_valid = false;
@@ -721,6 +731,7 @@ static void free_queries(icpx_ctx* c)
   dev_free(&c->d_ovf_list);
   dev_free(&c->d_ovf_best);
   dev_free(&c->d_fallback);
+  dev_free(&c->d_bail);
   dev_free(&c->d_cert);
   dev_free(&c->d_lead);
   dev_free(&c->d_setmask);
@@ -2000,7 +2011,23 @@ static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, uns
       launch_ev(c, false, k_fallback<L>, pgrid, 256, st, lo, *wide);
     else
       launch_ev(c, false, k_search3p<L>, pgrid, 256, st, lo);
-    launch_ev(c, false, k_search3w<L, true>, wgrid, 64, st, hi);
+    if (a.bail_ticks && wide)
+    {
+      // (the walk over a long list gives up on batches as a whole pass does, onto the list of
+      // its own that the launch behind it serves one wavefront per query)
+      launch_ev(c, false, k_search3w<L, true, true>, wgrid, 64, st, hi);
+      Search3Args ab = a;
+      ab.qlist = a.bail_list;
+      ab.count_slot = a.bail_slot;
+      ab.list_lo = 0;
+      ab.list_hi = INT64_MAX;
+      ab.setmask = nullptr;
+      ab.bail_ticks = 0u;
+      k_reset_pools<<<1, 64, 0, st>>>(a.counters); // (the walk has drawn from them)
+      launch_ev(c, false, k_fallback<L>, pgrid, 256, st, ab, *wide);
+    }
+    else
+      launch_ev(c, false, k_search3w<L, true>, wgrid, 64, st, hi);
   }
   else if (wide && pgrid && mode == 1)
     launch_ev(c, false, k_fallback<L>, pgrid, 256, st, a, *wide);
@@ -2021,9 +2048,11 @@ static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, uns
       // lanes, should they be many)
       Search3Args ab = a;
       ab.qlist = a.bail_list;
+      ab.count_slot = a.bail_slot;
       ab.use_hint = 1;
       ab.setmask = nullptr;
       ab.bail_ticks = 0u;
+      k_reset_pools<<<1, 64, 0, st>>>(a.counters); // (the walk has drawn from them)
       launch_ev(c, false, k_fallback<L>, pgrid, 256, st, ab, *wide);
     }
   }
@@ -2335,6 +2364,7 @@ static int run_search3(icpx_ctx* c)
     ALLOC(c->d_ovf_list, c->nq);
     ALLOC(c->d_ovf_best, c->nq);
     ALLOC(c->d_fallback, c->nq);
+    ALLOC(c->d_bail, c->nq);
     ALLOC(c->d_cert, c->nq);
     ALLOC(c->d_lead, c->nq);
     ALLOC(c->d_setmask, (c->nq + 63) / 64 + 1);
@@ -2370,6 +2400,10 @@ static int run_search3(icpx_ctx* c)
   a.qlist = nullptr;
   a.bail_list = nullptr;
   a.bail_ticks = 0u;
+  a.bail_mean = c->bail_mode == 1 ? 1 : 0;
+  a.count_slot = 3;
+  a.bail_slot = 2;
+  a.small_limit = FALLBACK_SMALL;
   a.list_lo = 0;
   a.list_hi = INT64_MAX;
   a.cap2 = c->cap2;
@@ -2514,12 +2548,16 @@ static int run_search3(icpx_ctx* c)
   // at least (the longest batch of an evenly meshed million triangles takes about 1 ms)
   // (only for a target whose triangles' sizes range widely, or when asked for: the kernel
   // that can give up is a build of its own, 3 % slower on every walk)
-  const bool whole_walk = !use_local && mode == 3 &&
-    (c->bail_mode > 1 || (c->bail_mode == 1 && c->mesh_grading > GRADED_MESH));
+  const bool graded = c->bail_mode > 1 || (c->bail_mode == 1 && c->mesh_grading > GRADED_MESH);
+  // (... and by a walk over a long list of a heavy cloud's leftovers, the other kernel that
+  // runs one walk per wavefront)
+  const bool whole_walk = graded && ((!use_local && mode == 3) || (use_local && mode == 1 && heavy_cloud(c)));
+  if (graded)
+    a.small_limit = 2u * FALLBACK_SMALL;
   if (whole_walk && ensure_heap(c, 64) == ICPX_OK)
   {
     const uint64_t per_wave = ((uint64_t)c->nq / 64u) / std::max(wgrid, 1u);
-    a.bail_list = c->d_fallback;
+    a.bail_list = c->d_bail;
     const uint64_t us = c->bail_mode > 1 ? (uint64_t)c->bail_mode
                                          : std::min<uint64_t>(std::max<uint64_t>(125u * per_wave, 800u), 1000000u);
     a.bail_ticks = (uint32_t)(us * 2400u / 64u); // (the shader clock at its 2.4 GHz: a lower clock makes the budget longer)

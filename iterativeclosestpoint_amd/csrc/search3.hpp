@@ -326,7 +326,7 @@ struct Search3Args
   float* lead;
   // A whole pass of the wavefront walk gives up on a batch that has been walking for
   // bail_ticks x 64 cycles of the shader clock (0: never): its queries go on this list (count in
-  // counters[3]) with the best triangle found so far as their start, and the kernel behind the
+  // counters[bail_slot]) with the best triangle found so far as their start, and the kernel behind the
   // walk (k_fallback) serves them one wavefront per query.  A few queries beside a patch of
   // triangles much smaller than their distance from it have thousands of boxes within their
   // bound; their batch of 64 then walks for as long as the rest of the pass takes together (a
@@ -334,6 +334,17 @@ struct Search3Args
   // 100, a cold pass of 15.7 ms instead of 1).
   uint32_t* bail_list;
   uint32_t bail_ticks;
+  int bail_mean; // 0: past the deadline is enough (tests); 1: ... and four times the pass's mean batch
+  // Which of the pass counters holds the length of qlist (3: the shortcut's / k_certify's
+  // leftovers; 2: the list of the queries given up on) and which one a walk that gives up
+  // counts on (2: the list is one of its own, so that a walk over a list can give up as well).
+  int count_slot, bail_slot;
+  // k_fallback: lists up to this length go one wavefront per query, longer ones to the pooled
+  // lanes (FALLBACK_SMALL; on a target whose triangles' sizes range widely twice that: a
+  // pooled lane has a query with thousands of boxes in reach to itself, and the pass waits
+  // for it, 5 ms for a list of 0.1 M where the wavefronts take 2; 0.3 M such queries cost the
+  // wavefronts 25 ms and the pooled lanes, which hold that many at once, the same 5)
+  uint32_t small_limit;
 };
 
 // the margin a query's search is widened by (see Search3Args::widen_max)
@@ -684,7 +695,7 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
   bool have = false, fin = false, need_bt = false, atleaf = false;
   bool dry = false; // the pools have run out (same for every lane of the wavefront)
   uint32_t tried = 0; // runs this wavefront has found used up
-  const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
+  const int64_t total = a.qlist ? (int64_t)a.counters[a.count_slot] : a.nq;
   if ((int64_t)blockIdx.x * 256 >= total)
     return; // a short list is served by the first blocks; the rest must not queue at the pool
   if (a.qlist && (total < a.list_lo || total >= a.list_hi))
@@ -981,13 +992,13 @@ constexpr uint32_t FALLBACK_SMALL = 98304;
 template <int L>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_fallback(Search3Args a, Search2Args w)
 {
-  const uint32_t total = a.counters[3];
+  const uint32_t total = a.counters[a.count_slot];
   if (total == 0u || (int64_t)total < a.list_lo || (int64_t)total >= a.list_hi)
     return; // (most converged passes: gone after one read; or the other kernel's list)
   Xf T;
   if (!load_xf(a.T, T))
     return; // the registration this pass belongs to has already stopped
-  if (total > FALLBACK_SMALL)
+  if (total > a.small_limit)
   {
     search3p_body<L>(a, T);
     return;
@@ -1181,7 +1192,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
   const int lane = threadIdx.x;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int d = a.tree.depth;
-  const int64_t total = a.qlist ? (int64_t)a.counters[3] : a.nq;
+  const int64_t total = a.qlist ? (int64_t)a.counters[a.count_slot] : a.nq;
   if ((int64_t)blockIdx.x * 64 >= total)
     return; // a short list is served by the first blocks; the rest must not queue at the pool
   if (a.qlist && (total < a.list_lo || total >= a.list_hi))
@@ -1740,7 +1751,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
               tsum = uni32(tsum);
               tcnt = uni32(tcnt);
               const uint32_t spent = now - walk_t0;
-              if (tcnt >= 64u && (uint64_t)(spent >> 2) * tcnt > 4ull * tsum)
+              if (!a.bail_mean || (tcnt >= 64u && (uint64_t)(spent >> 2) * tcnt > 4ull * tsum))
                 go = false;
               else
                 walk_end = max(now + (spent >> 2), 1u);
@@ -1755,7 +1766,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
       const unsigned long long mb = __ballot(active);
       uint32_t tb = 0u;
       if (lane == 0)
-        tb = atomicAdd(&a.counters[3], (uint32_t)__popcll(mb));
+        tb = atomicAdd(&a.counters[a.bail_slot], (uint32_t)__popcll(mb));
       tb = uni32(tb);
       if (active)
       {

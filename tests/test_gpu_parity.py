@@ -352,6 +352,22 @@ def test_graded_mesh_and_batches_given_up_on(icpx, synth, oracle):
     # the oracle's own loop from the same start
     To = mesh.icp(src, metric=1, max_iter=12, max_landmarks=len(src), max_dist=10.0)[0]
     assert rel_err(runs[0][0], To) < 1e-6
+    # a cloud whose given-up queries are more than go one wavefront each: the pooled lanes
+    # serve them, drawing from the pools the walk has just drawn from
+    c2 = synth.config_c6(300, 200, 420_000)
+    src2 = c2["source_xyz"]
+    ctx = icpx.Context(0)
+    ctx.set_persistent(3)
+    ctx.set_bail(2)
+    ctx.set_target(xyz, tri)
+    ctx.set_source(src2)
+    got = ctx.correspond(np.eye(4), max_dist=10.0)
+    assert ctx.debug_counters()["pool"] > 2 * 98304, ctx.debug_counters()
+    pick = np.arange(0, len(src2), 5)
+    ref = mesh.correspond(src2[pick], step=1, max_dist=10.0, grid=True)
+    for k in ("cell", "dist", "closest"):
+        assert np.array_equal(got[k][pick], ref[k]), k
+    ctx.close()
 
 
 def test_vtkicp_surface(icpx, synth, small):
