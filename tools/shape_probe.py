@@ -93,6 +93,24 @@ def case(name):
         sel = np.argsort(np.linalg.norm(cen - cen[12345], axis=1))[:n]
         xyz2, tri2 = refine(xyz, tri, sel, 64)
         c.update(target_xyz=xyz2, target_tri=tri2, source_normals=None, metric=1)
+    elif name == "flat":    # a flat square of a million triangles (a singular system for the solvers)
+        n = 708
+        g = np.linspace(0.0, 1.0, n, dtype=np.float64)
+        X, Y = np.meshgrid(g, g, indexing="ij")
+        xyz = np.stack([X, Y, 0.0 * X], -1).reshape(-1, 3).astype(np.float32)
+        i, j = np.meshgrid(np.arange(n - 1), np.arange(n - 1), indexing="ij")
+        p00 = (i * n + j).ravel()
+        tri = np.concatenate([np.stack([p00, p00 + n, p00 + n + 1], -1), np.stack([p00, p00 + n + 1, p00 + 1], -1)]).astype(np.int32)
+        pts, f, fn = S.sample_surface(xyz, tri, 1_000_000)
+        M = S.rigid(rx=2.0, t=(0.002, -0.001, 0.01))
+        c = dict(target_xyz=xyz, target_tri=tri, source_xyz=S.apply(M, pts), source_normals=None, metric=1,
+                 max_dist=10.0, truth=M)
+    elif name == "apart":   # two of C3's tori a hundred units apart, the cloud on one of them
+        c = S.config_c3(nu=700, nv=350)
+        xyz, tri = c["target_xyz"], c["target_tri"]
+        xyz2 = np.concatenate([xyz, xyz + np.float32([100.0, 0, 0])])
+        tri2 = np.concatenate([tri, tri + len(xyz)]).astype(np.int32)
+        c.update(target_xyz=xyz2, target_tri=tri2, source_normals=None, metric=1)
     elif name == "cube":    # a million points on the twelve triangles of a cube
         v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float32)
         t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5],
