@@ -111,6 +111,17 @@ def case(name):
         xyz2 = np.concatenate([xyz, xyz + np.float32([100.0, 0, 0])])
         tri2 = np.concatenate([tri, tri + len(xyz)]).astype(np.int32)
         c.update(target_xyz=xyz2, target_tri=tri2, source_normals=None, metric=1)
+    elif name == "sliver":  # every triangle a sliver: 4000 x 125 grid lines, sides 32 to 1
+        c = S.config_c3(nu=4000, nv=125)
+        c.update(source_normals=None, metric=1)
+    elif name == "fewpts":  # a thousand points on ten million triangles
+        c = S.config_c4(npts=1000)
+    elif name == "twosheet":  # two copies of C3's torus 1e-5 apart: two contenders for every point
+        c = S.config_c3(nu=700, nv=350)
+        xyz, tri = c["target_xyz"], c["target_tri"]
+        xyz2 = np.concatenate([xyz, xyz + np.float32([1e-5, 1e-5, 1e-5])])
+        tri2 = np.concatenate([tri, tri + len(xyz)]).astype(np.int32)
+        c.update(target_xyz=xyz2, target_tri=tri2, source_normals=None, metric=1)
     elif name == "cube":    # a million points on the twelve triangles of a cube
         v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float32)
         t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5],
