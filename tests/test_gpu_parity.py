@@ -1097,6 +1097,63 @@ def test_scene_far_from_the_origin(icpx, synth, oracle):
     ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["two_sheets", "slivers", "flat"])
+def test_near_coincident_sheets_slivers_and_a_flat_target(icpx, synth, oracle, shape):
+    """Targets that stress one rule each.  two_sheets: a second copy of the surface 1e-5 away,
+    so every query has two contenders that share no edge and differ in the sixth digit (pair
+    and set certificates between triangles that are not neighbours).  slivers: every triangle
+    thirty times as long as wide (boxes that overlap dozens of others).  flat: a planar square,
+    a singular system for the point-to-plane solve, all boxes of zero height.  Rows are the
+    oracle's on a cold pass, a hinted one and after small and large moves, on a noisy and a
+    clean cloud; the registration is the oracle's loop's."""
+    if shape == "two_sheets":
+        xyz0, tri0 = synth.bumpy_torus(120, 60)
+        xyz = np.concatenate([xyz0, xyz0 + np.float32([1e-5, 1e-5, 1e-5])])
+        tri = np.concatenate([tri0, tri0 + len(xyz0)]).astype(np.int32)
+    elif shape == "slivers":
+        xyz, tri = synth.bumpy_torus(960, 30)
+    else:
+        n = 100
+        g = np.linspace(0.0, 1.0, n)
+        X, Y = np.meshgrid(g, g, indexing="ij")
+        xyz = np.stack([X, Y, 0.0 * X], -1).reshape(-1, 3).astype(np.float32)
+        i, j = np.meshgrid(np.arange(n - 1), np.arange(n - 1), indexing="ij")
+        p00 = (i * n + j).ravel()
+        tri = np.concatenate([np.stack([p00, p00 + n, p00 + n + 1], -1),
+                              np.stack([p00, p00 + n + 1, p00 + 1], -1)]).astype(np.int32)
+    pts, f, fn = synth.sample_surface(xyz, tri, 300_000, seed=29)
+    noise = np.stack([synth.gaussian(31, 2 * k, len(pts)) for k in range(3)], -1) * 2e-3
+    M = synth.rigid(ry=1.0 if shape != "flat" else 0.0, rx=1.0, t=(0.004, -0.002, 0.006))
+    mesh = oracle.Mesh(xyz, tri)
+    for label, cloud in (("noisy", pts.astype(np.float64) + noise), ("clean", pts.astype(np.float64))):
+        src = synth.apply(M, cloud)
+        ctx = icpx.Context(0)
+        ctx.set_target(xyz, tri)
+        ctx.set_source(src)
+        T = np.eye(4)
+        for m in (0, 0, 1e-5, 1e-5, 3e-3, 1e-5, 1e-6, 1e-6):
+            T = synth.rigid(t=(m, -m, 0.5 * m)) @ T
+            got = ctx.correspond(T, step=1, max_dist=10.0)
+            pick = np.arange(0, len(src), 11)
+            ref = mesh.correspond(src[pick], T=T, step=1, max_dist=10.0, grid=True)
+            for k in ("cell", "dist", "closest"):
+                assert np.array_equal(got[k][pick], ref[k]), (shape, label, m, k)
+        if label == "clean":
+            sub = src[::10]
+            ctx.set_source(sub)
+            p = icpx.default_params()
+            p.metric, p.max_iterations, p.max_landmarks, p.max_distance = 1, 12, len(sub), 10.0
+            Tg, it, mean, st = ctx.run(p)
+            To, ito, meano = mesh.icp(sub, metric=1, max_iter=12, max_landmarks=len(sub), max_dist=10.0)[:3]
+            assert it == ito
+            # (a planar target leaves the in-plane motion undetermined: the solver's answer
+            # there is whatever its pivoting makes of a singular system, equal to the oracle's
+            # because the sums and the elimination order are)
+            assert np.abs(Tg - To).max() < (1e-7 if shape == "flat" else 1e-9), np.abs(Tg - To).max()
+        ctx.close()
+
+
 def _point_triangle_dist(q, P):
     """Distances from points q (n,3) to triangles P (m,3,3), all pairs, float64 (Ericson)."""
     a, b, c = P[None, :, 0], P[None, :, 1], P[None, :, 2]
