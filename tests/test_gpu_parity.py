@@ -1154,6 +1154,20 @@ def test_near_coincident_sheets_slivers_and_a_flat_target(icpx, synth, oracle, s
         ctx.close()
 
 
+@pytest.mark.gpu
+def test_every_policy_gives_the_same_rows(icpx):
+    """Random settings of the policy knobs (which kernel walks, lists, certificates, batches
+    given up on, who weighs the sets, seeds, query order, lean and anchored passes) on a clean,
+    a noisy, a graded and a doubled surface: rows equal to the plainest setting's bit for bit
+    over twelve passes of moves from none to large, registrations equal to rounding."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "policy_fuzz", os.path.join(os.path.dirname(__file__), "..", "tools", "policy_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.fuzz(8, 17, only=("noisy", "graded", "graded noisy", "two sheets")) is None
+
+
 def _point_triangle_dist(q, P):
     """Distances from points q (n,3) to triangles P (m,3,3), all pairs, float64 (Ericson)."""
     a, b, c = P[None, :, 0], P[None, :, 1], P[None, :, 2]

@@ -1,0 +1,97 @@
+"""Every policy, the same rows: mid-size scenes served under random settings of the library's
+policy knobs (which kernel walks, lists or none, certificates, batches given up on, who weighs
+the sets, seeds, query order, lean and anchored passes), each compared bit for bit with the
+plainest setting (pooled lanes over the tree, nothing kept between passes).
+
+    python tools/policy_fuzz.py [combos per scene] [seed] [big]
+
+big: a million triangles and three times the points.
+
+Prints one line per scene; exits 1 at the first difference, naming the knobs.
+"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from iterativeclosestpoint_amd import icpx, synth as S  # noqa: E402
+
+KNOBS = dict(
+    local=[0, 1, 2, 3], persistent=[1, 3, 4], bail=[0, 1, 2, 20, 200], certify_min=[1000, 100_000, 4_000_000],
+    noisy_policy=[0, 1], weigh=[0, 1, 2, 3], seed=[0, 1, 2], query_curve=[0, 1], finalize=[0, 1, 2],
+    lean=[0, 1, 2, 3], anchor=[0, 1], wave_blocks=[1, 2, 8])
+PLAIN = dict(local=0, persistent=1, bail=0, lean=0, anchor=0)
+
+
+def scenes(big):
+    nu, nv, mul = (1000, 500, 3) if big else (400, 200, 1)
+    for name, grade, noise, npts in (("clean", 0.0, 0.0, 400_000), ("noisy", 0.0, 2e-3, 400_000),
+                                     ("graded", 0.97, 0.0, 400_000), ("graded noisy", 0.97, 4e-3, 300_000),
+                                     ("sparse", 0.0, 1e-3, 3_000), ("two sheets", 0.0, 1e-4, 300_000)):
+        xyz, tri = S.bumpy_torus(nu, nv, grade=grade)
+        if name == "two sheets":
+            tri = np.concatenate([tri, tri + len(xyz)]).astype(np.int32)
+            xyz = np.concatenate([xyz, xyz + np.float32([1e-5, 1e-5, 1e-5])])
+        pts, f, fn = S.sample_surface(xyz, tri, npts * mul, seed=41)
+        cloud = pts.astype(np.float64)
+        if noise:
+            cloud = cloud + np.stack([S.gaussian(43, 2 * k, npts * mul) for k in range(3)], -1) * noise
+        M = S.rigid(ry=3.0, t=(0.01, 0.01, -0.01))
+        yield name, xyz, tri, S.apply(M, cloud)
+
+
+def serve(xyz, tri, src, knobs, moves):
+    ctx = icpx.Context(0)
+    for k, v in knobs.items():
+        getattr(ctx, "set_" + k)(v)
+    ctx.set_target(xyz, tri)
+    ctx.set_source(src)
+    out = []
+    T = np.eye(4)
+    for m in moves:
+        T = S.rigid(rz=20 * m, t=(m, -m, 0.5 * m)) @ T
+        got = ctx.correspond(T, step=1, max_dist=10.0)
+        out.append((got["cell"].copy(), got["dist"].copy(), got["closest"].copy()))
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = 1, 30, len(src), 10.0
+    Tr, it, mean, st = ctx.run(p)
+    ctx.close()
+    return out, (Tr.copy(), it, mean, st)
+
+
+def fuzz(ncombo, seed, big=False, only=None):
+    """None if every setting agrees, else a description of the first difference."""
+    rng = np.random.default_rng(seed)
+    moves = (0, 0, 1e-7, 1e-5, 1e-5, 1e-3, 1e-6, 3e-2, 1e-6, 1e-6, 1e-4, 0)
+    for name, xyz, tri, src in scenes(big):
+        if only and name not in only:
+            continue
+        t0 = time.perf_counter()
+        rows0, run0 = serve(xyz, tri, src, PLAIN, moves)
+        for c in range(ncombo):
+            knobs = {k: int(rng.choice(v)) for k, v in KNOBS.items() if rng.random() < 0.6}
+            rows, run = serve(xyz, tri, src, knobs, moves)
+            for i, (a, b) in enumerate(zip(rows0, rows)):
+                for what, x, y in zip(("cell", "dist", "closest"), a, b):
+                    if not np.array_equal(x, y):
+                        bad = np.flatnonzero((x != y).reshape(len(x), -1).any(1))
+                        return ("scene %r pass %d %s at %d queries (first %s) under %r" %
+                                (name, i, what, len(bad), bad[:5], knobs))
+            # (the sums' order follows the query order and the finalize build: the loops agree
+            # to rounding, not in their bits; a converged clean cloud's mean distance is itself
+            # rounding, 1e-8, and follows the transform's eleventh digit)
+            if not (np.abs(run0[0] - run[0]).max() < 1e-9 and run0[1] == run[1] and run0[3] == run[3]
+                    and abs(run0[2] - run[2]) <= 1e-9 * abs(run0[2]) + 1e-11):
+                return "scene %r registration under %r: %r against %r" % (name, knobs, run, run0)
+        print("%-14s %d triangles %d points: %d settings agree with the plain one on %d passes and the registration (%.1f s)"
+              % (name, len(tri), len(src), ncombo, len(moves), time.perf_counter() - t0), flush=True)
+    return None
+
+
+if __name__ == "__main__":
+    bad = fuzz(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 7,
+               len(sys.argv) > 3 and sys.argv[3] == "big")
+    if bad:
+        print("DIFFERENT:", bad)
+        sys.exit(1)
