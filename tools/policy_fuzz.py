@@ -38,10 +38,13 @@ def scenes(big):
         if noise:
             cloud = cloud + np.stack([S.gaussian(43, 2 * k, npts * mul) for k in range(3)], -1) * noise
         M = S.rigid(ry=3.0, t=(0.01, 0.01, -0.01))
-        yield name, xyz, tri, S.apply(M, cloud)
+        yield name, xyz, tri, S.apply(M, cloud), 10.0
+    # partial overlap, a fifth of the cloud outliers, a threshold of 2 % of the diagonal
+    c = S.config_c5(nu=nu, nv=nv, npts=300_000 * mul)
+    yield "partial", c["target_xyz"], c["target_tri"], c["source_xyz"], c["max_dist"]
 
 
-def serve(xyz, tri, src, knobs, moves):
+def serve(xyz, tri, src, max_dist, knobs, moves):
     ctx = icpx.Context(0)
     for k, v in knobs.items():
         getattr(ctx, "set_" + k)(v)
@@ -51,10 +54,10 @@ def serve(xyz, tri, src, knobs, moves):
     T = np.eye(4)
     for m in moves:
         T = S.rigid(rz=20 * m, t=(m, -m, 0.5 * m)) @ T
-        got = ctx.correspond(T, step=1, max_dist=10.0)
-        out.append((got["cell"].copy(), got["dist"].copy(), got["closest"].copy()))
+        got = ctx.correspond(T, step=1, max_dist=max_dist)
+        out.append((got["cell"].copy(), got["dist"].copy(), got["closest"].copy(), got["src_index"].copy()))
     p = icpx.default_params()
-    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = 1, 30, len(src), 10.0
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = 1, 30, len(src), max_dist
     Tr, it, mean, st = ctx.run(p)
     ctx.close()
     return out, (Tr.copy(), it, mean, st)
@@ -64,16 +67,18 @@ def fuzz(ncombo, seed, big=False, only=None):
     """None if every setting agrees, else a description of the first difference."""
     rng = np.random.default_rng(seed)
     moves = (0, 0, 1e-7, 1e-5, 1e-5, 1e-3, 1e-6, 3e-2, 1e-6, 1e-6, 1e-4, 0)
-    for name, xyz, tri, src in scenes(big):
+    for name, xyz, tri, src, max_dist in scenes(big):
         if only and name not in only:
             continue
         t0 = time.perf_counter()
-        rows0, run0 = serve(xyz, tri, src, PLAIN, moves)
+        rows0, run0 = serve(xyz, tri, src, max_dist, PLAIN, moves)
         for c in range(ncombo):
             knobs = {k: int(rng.choice(v)) for k, v in KNOBS.items() if rng.random() < 0.6}
-            rows, run = serve(xyz, tri, src, knobs, moves)
+            rows, run = serve(xyz, tri, src, max_dist, knobs, moves)
             for i, (a, b) in enumerate(zip(rows0, rows)):
-                for what, x, y in zip(("cell", "dist", "closest"), a, b):
+                for what, x, y in zip(("cell", "dist", "closest", "src_index"), a, b):
+                    if x.shape != y.shape:
+                        return "scene %r pass %d: %d rows against %d under %r" % (name, i, len(y), len(x), knobs)
                     if not np.array_equal(x, y):
                         bad = np.flatnonzero((x != y).reshape(len(x), -1).any(1))
                         return ("scene %r pass %d %s at %d queries (first %s) under %r" %
