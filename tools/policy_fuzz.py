@@ -3,9 +3,10 @@ policy knobs (which kernel walks, lists or none, certificates, batches given up 
 the sets, seeds, query order, lean and anchored passes), each compared bit for bit with the
 plainest setting (pooled lanes over the tree, nothing kept between passes).
 
-    python tools/policy_fuzz.py [combos per scene] [seed] [big]
+    python tools/policy_fuzz.py [combos per scene] [seed] [big|huge]
 
-big: a million triangles and three times the points.
+big: a million triangles and three times the points; huge: ten million triangles and sixteen
+million points, the two noisy scenes only.
 
 Prints one line per scene; exits 1 at the first difference, naming the knobs.
 """
@@ -24,11 +25,13 @@ KNOBS = dict(
 PLAIN = dict(local=0, persistent=1, bail=0, lean=0, anchor=0)
 
 
-def scenes(big):
-    nu, nv, mul = (1000, 500, 3) if big else (400, 200, 1)
+def scenes(big, only=None):
+    nu, nv, mul = (2500, 2000, 40) if big == "huge" else (1000, 500, 3) if big else (400, 200, 1)
     for name, grade, noise, npts in (("clean", 0.0, 0.0, 400_000), ("noisy", 0.0, 2e-3, 400_000),
                                      ("graded", 0.97, 0.0, 400_000), ("graded noisy", 0.97, 4e-3, 300_000),
                                      ("sparse", 0.0, 1e-3, 3_000), ("two sheets", 0.0, 1e-4, 300_000)):
+        if only and name not in only:
+            continue
         xyz, tri = S.bumpy_torus(nu, nv, grade=grade)
         if name == "two sheets":
             tri = np.concatenate([tri, tri + len(xyz)]).astype(np.int32)
@@ -39,6 +42,8 @@ def scenes(big):
             cloud = cloud + np.stack([S.gaussian(43, 2 * k, npts * mul) for k in range(3)], -1) * noise
         M = S.rigid(ry=3.0, t=(0.01, 0.01, -0.01))
         yield name, xyz, tri, S.apply(M, cloud), 10.0
+    if only and "partial" not in only:
+        return
     # partial overlap, a fifth of the cloud outliers, a threshold of 2 % of the diagonal
     c = S.config_c5(nu=nu, nv=nv, npts=300_000 * mul)
     yield "partial", c["target_xyz"], c["target_tri"], c["source_xyz"], c["max_dist"]
@@ -67,14 +72,15 @@ def fuzz(ncombo, seed, big=False, only=None):
     """None if every setting agrees, else a description of the first difference."""
     rng = np.random.default_rng(seed)
     moves = (0, 0, 1e-7, 1e-5, 1e-5, 1e-3, 1e-6, 3e-2, 1e-6, 1e-6, 1e-4, 0)
-    for name, xyz, tri, src, max_dist in scenes(big):
-        if only and name not in only:
-            continue
-        t0 = time.perf_counter()
+    for name, xyz, tri, src, max_dist in scenes(big, only):
+        t0 = tick = time.perf_counter()
         rows0, run0 = serve(xyz, tri, src, max_dist, PLAIN, moves)
         for c in range(ncombo):
             knobs = {k: int(rng.choice(v)) for k, v in KNOBS.items() if rng.random() < 0.6}
             rows, run = serve(xyz, tri, src, max_dist, knobs, moves)
+            if time.perf_counter() - tick > 30.0:   # (a sign of life for whoever watches a long run)
+                tick = time.perf_counter()
+                print("  ... %s: %d of %d settings" % (name, c + 1, ncombo), file=sys.stderr, flush=True)
             for i, (a, b) in enumerate(zip(rows0, rows)):
                 for what, x, y in zip(("cell", "dist", "closest", "src_index"), a, b):
                     if x.shape != y.shape:
@@ -96,7 +102,8 @@ def fuzz(ncombo, seed, big=False, only=None):
 
 if __name__ == "__main__":
     bad = fuzz(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 7,
-               len(sys.argv) > 3 and sys.argv[3] == "big")
+               sys.argv[3] if len(sys.argv) > 3 else False,
+               only=("noisy", "graded noisy") if len(sys.argv) > 3 and sys.argv[3] == "huge" else None)
     if bad:
         print("DIFFERENT:", bad)
         sys.exit(1)
