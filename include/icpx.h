@@ -96,7 +96,12 @@ extern "C"
 
   /* Source points (float, as vtkICP requires: ICP/vtkICP.cxx:145-150) and
    * optional per-point normals (needed by the symmetric metric; the reference
-   * takes them from vtkPolyDataNormals, ICP/vtkPolyDataCorrespondenceFilter.cxx:457-471). */
+   * takes them from vtkPolyDataNormals, ICP/vtkPolyDataCorrespondenceFilter.cxx:457-471).
+   * A coordinate that is not a number, or beyond 1e12 in magnitude, is ICPX_E_INVALID and
+   * leaves the context without a source (the reference's locator derives a bucket index from
+   * such a point, which is undefined; here the kernels' pruning bounds assume that a moved
+   * point's squared distances are finite in single precision).  Transforms handed in are held
+   * to 1e6 in the 3x3 and 1e18 in the translation for the same reason. */
   int icpx_set_source(
     icpx_ctx* ctx, const float* xyz, int64_t np, const float* normals_or_null);
 
@@ -251,6 +256,10 @@ extern "C"
 #define ICPX_RUN_MAX_ITERATIONS 0 /* ran MaximumNumberOfIterations */
 #define ICPX_RUN_CONVERGED 1      /* mean distance <= MaximumMeanDistance */
 #define ICPX_RUN_TOO_FEW 2        /* too few correspondences; transform kept */
+#define ICPX_RUN_DIVERGED 3       /* a solve gave a transform that is not finite (sums that carry a NaN, \
+                                     from normals that are not numbers) or beyond the limits of        \
+                                     icpx_set_source (a system singular to within rounding); the last  \
+                                     good transform kept */
 
   /* The whole loop of vtkICP::InternalUpdate (ICP/vtkICP.cxx:189-246):
    * search, optional mean-distance early-out, solve, T <- M*T, repeated.

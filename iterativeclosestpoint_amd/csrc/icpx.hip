@@ -455,7 +455,7 @@ struct icpx_ctx
   uint32_t* d_ovf_list = nullptr;
   double* d_ovf_best = nullptr;
   float scene_max = 0.f;
-  float src_max = 0.f;  // largest |coordinate| of the source points (-1: not finite)
+  float src_max = 0.f;  // largest |coordinate| of the source points
   int use_anchor = 1;   // anchored passes (cert.hpp)
   int exhaustive = 0;
   double build_seconds = 0.0;
@@ -1300,8 +1300,9 @@ extern "C" int icpx_set_target(icpx_ctx* c, const float* xyz, int64_t nv, const 
     for (int a = 0; a < 3; a++)
     {
       float v = xyz[3 * i + a];
-      if (!std::isfinite(v))
-        return fail(ICPX_E_INVALID, "icpx_set_target: point %lld is not finite", (long long)i);
+      if (!(std::fabs(v) <= 1e12f)) // (squared distances stay finite in single precision)
+        return fail(ICPX_E_INVALID, "icpx_set_target: point %lld is not a number, or beyond 1e12 in magnitude",
+          (long long)i);
       lo[a] = v < lo[a] ? v : lo[a];
       hi[a] = v > hi[a] ? v : hi[a];
     }
@@ -1772,10 +1773,15 @@ extern "C" int icpx_set_source(icpx_ctx* c, const float* xyz, int64_t np, const 
   HIPCHK(hipStreamSynchronize(c->stream));
   dev_free(&d_max);
   std::memcpy(&c->src_max, &bits, sizeof(bits));
-  if (!std::isfinite(c->src_max))
-    c->src_max = -1.f; // (no bound: no anchored passes)
-  c->np = np;
   c->src_version++;
+  // (the bits of a NaN order above those of every number, so the maximum shows one)
+  if (!(c->src_max <= 1e12f))
+  {
+    c->np = 0; // (what was uploaded is not searched)
+    c->src_max = 0.f;
+    return fail(ICPX_E_INVALID, "icpx_set_source: a coordinate is not a number, or beyond 1e12 in magnitude");
+  }
+  c->np = np;
   return ICPX_OK;
 }
 
@@ -2810,6 +2816,8 @@ static int check_call(icpx_ctx* c, const double* T, int metric, int use_sn)
   for (int i = 0; i < 16; i++)
     if (!std::isfinite(T[i]))
       return fail(ICPX_E_INVALID, "transform is not finite");
+  if (!icpx_core::transform_usable(T))
+    return fail(ICPX_E_INVALID, "transform beyond 1e6 in its 3x3 or 1e18 in its translation");
   return ICPX_OK;
 }
 
@@ -3899,7 +3907,6 @@ extern "C" int icpx_run(icpx_ctx* c, const icpx_params* p, double T_out[16], int
     }
     if (rc)
       return rc;
-    iters++;
     double R[16];
     for (int r = 0; r < 4; r++)
       for (int k = 0; k < 4; k++)
@@ -3909,6 +3916,12 @@ extern "C" int icpx_run(icpx_ctx* c, const icpx_params* p, double T_out[16], int
           acc += M[4 * r + j] * T[4 * j + k];
         R[4 * r + k] = acc;
       }
+    if (!icpx_core::transform_usable(R))
+    {
+      status = ICPX_RUN_DIVERGED; // (as the device's loop: the last good transform is kept)
+      break;
+    }
+    iters++;
     std::memcpy(T, R, sizeof(R));
   }
   std::memcpy(T_out, T, sizeof(T));

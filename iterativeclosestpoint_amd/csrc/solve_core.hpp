@@ -348,6 +348,23 @@ ICPX_HD inline void centred_system(const M3& A, const M3& B, const M3& N, const 
 }
 
 
+// Whether a row-major 4x4 can be handed to the search kernels: every entry a number, the 3x3
+// within 1e6 and the translation within 1e18 in magnitude (source coordinates are held to
+// 1e12, so a moved point and the squares of its distances stay finite in single precision;
+// the kernels' pruning bounds assume that).  A solve of sums that carry a NaN (normals that
+// are not numbers) or of a system singular to within rounding does not pass.
+ICPX_HD inline bool transform_usable(const double* T)
+{
+  bool ok = true;
+  for (int r = 0; r < 3; r++)
+  {
+    for (int k = 0; k < 3; k++)
+      ok = ok && fabs(T[4 * r + k]) <= 1e6;
+    ok = ok && fabs(T[4 * r + 3]) <= 1e18;
+  }
+  return ok; // (a NaN fails every comparison)
+}
+
 // Returns ICPX_OK, ICPX_E_FEW (M = identity) or ICPX_E_INVALID; n and the mean distance
 // |s - t| are reported in every case.
 ICPX_HD inline int solve_moments(int metric, const double* sums, const double* origin, double* M,

@@ -108,8 +108,6 @@ __device__ inline void solve_and_publish(RunState* s, const double* __restrict__
     }
     else
     {
-      iters++;
-      s->iters = iters;
       double Tn[16];
       for (int r = 0; r < 4; r++)
         for (int k = 0; k < 4; k++)
@@ -118,8 +116,20 @@ __device__ inline void solve_and_publish(RunState* s, const double* __restrict__
           for (int j = 0; j < 4; j++)
             acc += M[4 * r + j] * Tm[4 * j + k];
           Tn[4 * r + k] = acc;
-          s->T[4 * r + k] = acc;
         }
+      // (a transform the search kernels cannot take, from sums that carry a NaN or a system
+      // singular to within rounding: the registration ends here with the last good one)
+      if (!icpx_core::transform_usable(Tn))
+      {
+        status = ICPX_RUN_DIVERGED;
+        done = 1;
+      }
+      else
+      {
+      iters++;
+      s->iters = iters;
+      for (int i = 0; i < 16; i++)
+        s->T[i] = Tn[i];
       // Is the coming pass an anchored one (cert.hpp)?  It is while no source point (within
       // src_rmax of the origin) is farther than anchor_reach from where the certificates'
       // transform has it: |dR p + dt| <= |dR|_F |p| + |dt|.
@@ -136,6 +146,7 @@ __device__ inline void solve_and_publish(RunState* s, const double* __restrict__
       }
       const double reach = (sqrt(r2) * (double)src_rmax + sqrt(t2)) * 1.000001;
       s->anchored = (cert_ok != 0 && anchor_reach > 0.f && reach <= (double)anchor_reach) ? 1 : 0;
+      }
     }
     if (done)
     {

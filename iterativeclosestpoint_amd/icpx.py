@@ -14,7 +14,7 @@ METRIC_POINT_TO_PLANE = 1
 METRIC_PLANE_TO_PLANE = 2
 
 E_INVALID, E_HIP, E_NOMEM, E_FEW = -1, -2, -3, -4
-RUN_MAX_ITERATIONS, RUN_CONVERGED, RUN_TOO_FEW = 0, 1, 2
+RUN_MAX_ITERATIONS, RUN_CONVERGED, RUN_TOO_FEW, RUN_DIVERGED = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ICPX_LIB") or os.path.join(_HERE, "libicpx.so")  # (ICPX_LIB: development builds)

@@ -108,8 +108,13 @@ def icp_loop(accumulate, allreduce, origin, metric, max_iterations, check_mean_d
         if rc == icpx.E_FEW:
             status = icpx.RUN_TOO_FEW
             break
+        Tn = M @ T  # vtkTransform PostMultiply + Concatenate (vtkICP.cxx:169,240)
+        # (a transform the library does not take, icpx.h: the loop ends with the last good one)
+        if not (np.all(np.abs(Tn[:3, :3]) <= 1e6) and np.all(np.abs(Tn[:3, 3]) <= 1e18)):
+            status = icpx.RUN_DIVERGED
+            break
         iters += 1
-        T = M @ T  # vtkTransform PostMultiply + Concatenate (vtkICP.cxx:169,240)
+        T = Tn
     return T, iters, mean, status
 
 

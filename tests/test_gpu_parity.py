@@ -1168,6 +1168,57 @@ def test_every_policy_gives_the_same_rows(icpx):
     assert mod.fuzz(8, 17, only=("noisy", "graded", "graded noisy", "two sheets")) is None
 
 
+@pytest.mark.gpu
+def test_inputs_that_are_not_numbers(icpx, synth, small):
+    """The reference leaves these undefined (its locator derives a bucket index from the
+    point).  Here a source coordinate that is not a number, or beyond 1e12, is refused and
+    leaves the context without a source; so is a transform beyond the limits; and normals
+    that are not numbers, which put a NaN into the sums and the solve, end the registration
+    with RUN_DIVERGED and the last good transform, on the device's loop and the host's."""
+    c, _ = small
+    xyz, tri, src = c["target_xyz"], c["target_tri"], c["source_xyz"]
+    ctx = icpx.Context(0)
+    ctx.set_target(xyz, tri)
+    p = icpx.default_params()
+    p.metric, p.max_iterations, p.max_landmarks, p.max_distance = 1, 10, len(src), 10.0
+    for bad in (np.nan, np.inf, -np.inf, 2e12):
+        pts = src.copy()
+        pts[len(pts) // 2, 1] = bad
+        with pytest.raises(icpx.IcpxError) as e:
+            ctx.set_source(pts)
+        assert e.value.code == icpx.E_INVALID
+        with pytest.raises(icpx.IcpxError):
+            ctx.run(p)      # (no source)
+    ctx.set_source(src)
+    T = np.eye(4)
+    T[0, 0] = 1e7
+    with pytest.raises(icpx.IcpxError):
+        ctx.correspond(T)
+    T = np.eye(4)
+    T[2, 3] = np.nan
+    with pytest.raises(icpx.IcpxError):
+        ctx.correspond(T)
+    bad_xyz = xyz.copy()
+    bad_xyz[3, 0] = np.nan
+    with pytest.raises(icpx.IcpxError):
+        icpx.Context(0).set_target(bad_xyz, tri)
+    good = ctx.run(p)
+    assert good[3] == icpx.RUN_MAX_ITERATIONS and np.isfinite(good[0]).all()
+    # cell normals of the user's with a NaN among them: rows carry it into the sums
+    cn = synth.face_normals(xyz, tri).astype(np.float32)
+    cn[::7, 2] = np.nan
+    ctx2 = icpx.Context(0)
+    ctx2.set_target(xyz, tri, cell_normals=cn)
+    ctx2.set_source(src)
+    Td, it, mean, st = ctx2.run(p)
+    assert st == icpx.RUN_DIVERGED and it == 0 and np.array_equal(Td, np.eye(4))
+    ctx2.set_allreduce(lambda sums: None)   # the loop on the host
+    Th, ith, meanh, sth = ctx2.run(p)
+    assert sth == icpx.RUN_DIVERGED and ith == 0 and np.array_equal(Th, np.eye(4))
+    ctx2.close()
+    ctx.close()
+
+
 def _point_triangle_dist(q, P):
     """Distances from points q (n,3) to triangles P (m,3,3), all pairs, float64 (Ericson)."""
     a, b, c = P[None, :, 0], P[None, :, 1], P[None, :, 2]
