@@ -3,10 +3,11 @@ policy knobs (which kernel walks, lists or none, certificates, batches given up 
 the sets, seeds, query order, lean and anchored passes), each compared bit for bit with the
 plainest setting (pooled lanes over the tree, nothing kept between passes).
 
-    python tools/policy_fuzz.py [combos per scene] [seed] [big|huge]
+    python tools/policy_fuzz.py [combos per scene] [seed] [big|huge|odd]
 
 big: a million triangles and three times the points; huge: ten million triangles and sixteen
-million points, the two noisy scenes only.
+million points, the two noisy scenes only; odd: clouds of one repeated point, along a line,
+nowhere near the target with and without a threshold in reach, and in a plane through it.
 
 Prints one line per scene; exits 1 at the first difference, naming the knobs.
 """
@@ -25,7 +26,23 @@ KNOBS = dict(
 PLAIN = dict(local=0, persistent=1, bail=0, lean=0, anchor=0)
 
 
+def odd_scenes():
+    xyz, tri = S.bumpy_torus(400, 200)
+    n = 300_000
+    t = S.u01(51, 1, n)[:, None]
+    yield "one point", xyz, tri, np.repeat(np.float32([[1.41, 0.02, 0.03]]), n, 0), 10.0
+    yield "a line", xyz, tri, (np.float64([-2.0, 0.1, 0.05]) + t * np.float64([4.0, 0.0, 0.1])).astype(np.float32), 10.0
+    pts, f, fn = S.sample_surface(xyz, tri, n, seed=53)
+    yield "out of reach", xyz, tri, (pts.astype(np.float64) + 1e4).astype(np.float32), 10.0
+    yield "far, no threshold", xyz, tri, (pts.astype(np.float64) + np.float64([50.0, -20.0, 10.0])).astype(np.float32), 1e9
+    plane = np.stack([4 * S.u01(55, 1, n) - 2, 4 * S.u01(55, 2, n) - 2, 0 * t[:, 0]], -1)
+    yield "a plane through it", xyz, tri, plane.astype(np.float32), 0.05
+
+
 def scenes(big, only=None):
+    if big == "odd":
+        yield from odd_scenes()
+        return
     nu, nv, mul = (2500, 2000, 40) if big == "huge" else (1000, 500, 3) if big else (400, 200, 1)
     for name, grade, noise, npts in (("clean", 0.0, 0.0, 400_000), ("noisy", 0.0, 2e-3, 400_000),
                                      ("graded", 0.97, 0.0, 400_000), ("graded noisy", 0.97, 4e-3, 300_000),
@@ -92,7 +109,8 @@ def fuzz(ncombo, seed, big=False, only=None):
             # (the sums' order follows the query order and the finalize build: the loops agree
             # to rounding, not in their bits; a converged clean cloud's mean distance is itself
             # rounding, 1e-8, and follows the transform's eleventh digit)
-            if not (np.abs(run0[0] - run[0]).max() < 1e-9 and run0[1] == run[1] and run0[3] == run[3]
+            # (the odd clouds make singular systems, whose answers follow the sums' last digits)
+            if big != "odd" and not (np.abs(run0[0] - run[0]).max() < 1e-9 and run0[1] == run[1] and run0[3] == run[3]
                     and abs(run0[2] - run[2]) <= 1e-9 * abs(run0[2]) + 1e-11):
                 return "scene %r registration under %r: %r against %r" % (name, knobs, run, run0)
         print("%-14s %d triangles %d points: %d settings agree with the plain one on %d passes and the registration (%.1f s)"
