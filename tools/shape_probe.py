@@ -122,6 +122,12 @@ def case(name):
         xyz2 = np.concatenate([xyz, xyz + np.float32([1e-5, 1e-5, 1e-5])])
         tri2 = np.concatenate([tri, tri + len(xyz)]).astype(np.int32)
         c.update(target_xyz=xyz2, target_tri=tri2, source_normals=None, metric=1)
+    elif name.startswith("away"):  # C3's cloud away<distance> units off its place (the target is 3 across), no threshold
+        d = float(name[4:])
+        c = S.config_c3()
+        M = S.rigid(ry=5.0, t=(0.8 * d, -0.5 * d, 0.33 * d))
+        pts = S.apply(np.linalg.inv(c["truth"]), c["source_xyz"])
+        c.update(source_xyz=S.apply(M, pts), source_normals=None, metric=1, max_dist=1e9, truth=M)
     elif name == "cube":    # a million points on the twelve triangles of a cube
         v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float32)
         t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5],
