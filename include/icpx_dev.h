@@ -68,6 +68,10 @@ extern "C"
    * (by default a batch must also have taken four times their mean).  Same results. */
   int icpx_set_bail(icpx_ctx* ctx, int microseconds);
 
+  /* Steps (boxes and leaves met) after which the pooled lanes give up on a query and leave it
+   * to the kernel behind them, one wavefront per query; 0: never.  Default 512. */
+  int icpx_set_step_budget(icpx_ctx* ctx, int steps);
+
   /* The fused finalize: 0 (default) = by the size of the cloud; 1 = the build that keeps the
    * metric's sums in registers; 2 = the build that accumulates them on the matrix core
    * (v_mfma_f64_16x16x4_f64 over a 16-vector per row).  The two add the rows up in different

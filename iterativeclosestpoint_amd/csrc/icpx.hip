@@ -365,6 +365,7 @@ struct icpx_ctx
   // of the previous pass that choose the radius
   int use_local = 1;
   int refill_override = 0; // pooled kernels' refill threshold (0 = by regime)
+  int step_budget = 512;   // steps after which the pooled lanes give up on a query (0: never)
   int bail_mode = 1;       // whole passes of the wavefront walk give up on long batches: 0 never,
                            // 1 on a target whose triangles' sizes range widely, after a time that goes by
                            // the cloud's size, else always, after that many microseconds
@@ -1097,6 +1098,16 @@ extern "C" int icpx_set_refill(icpx_ctx* c, int lanes)
   if (lanes < 0 || lanes > 64)
     return fail(ICPX_E_INVALID, "refill threshold must be 0 (by regime) or 1..64 lanes (got %d)", lanes);
   c->refill_override = lanes;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_step_budget(icpx_ctx* c, int steps)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  if (steps < 0)
+    return fail(ICPX_E_INVALID, "step budget must be 0 (none) or positive, got %d", steps);
+  c->step_budget = steps;
   return ICPX_OK;
 }
 
@@ -2001,6 +2012,25 @@ template <int L>
 static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, unsigned pgrid,
   unsigned wgrid, int mode, const Search2Args* wide, hipStream_t st)
 {
+  // The queries a walk gave up on (the batches of the wavefront walk past their deadline, the
+  // queries of the pooled lanes past their step budget), one wavefront each; batches' queries,
+  // should they be many, on the pooled lanes (most of them are their batch's bystanders).
+  auto given_up = [&](const Search3Args& from) {
+    Search3Args ab = from;
+    ab.qlist = from.bail_list;
+    ab.count_slot = from.bail_slot;
+    ab.list_lo = 0;
+    ab.list_hi = INT64_MAX;
+    ab.use_hint = 1;
+    ab.setmask = nullptr;
+    ab.bail_ticks = 0u;
+    ab.step_budget = 0u;
+    if (from.bail_ticks)
+      k_reset_pools<<<1, 64, 0, st>>>(from.counters); // (the walk has drawn from them)
+    else
+      ab.small_limit = 0xffffffffu; // (given up on one by one: every one of them is a long walk)
+    launch_ev(c, false, k_fallback<L>, pgrid, 256, st, ab, *wide);
+  };
   if (pgrid && mode == 1 && a.qlist && a.cert && heavy_cloud(c))
   {
     // The leftovers of a large cloud: the host does not know how many there are.  Most of
@@ -2017,26 +2047,21 @@ static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, uns
       launch_ev(c, false, k_fallback<L>, pgrid, 256, st, lo, *wide);
     else
       launch_ev(c, false, k_search3p<L>, pgrid, 256, st, lo);
+    // (the walk over a long list gives up on batches as a whole pass does, onto the list of
+    // its own that the launch behind it serves one wavefront per query)
     if (a.bail_ticks && wide)
-    {
-      // (the walk over a long list gives up on batches as a whole pass does, onto the list of
-      // its own that the launch behind it serves one wavefront per query)
       launch_ev(c, false, k_search3w<L, true, true>, wgrid, 64, st, hi);
-      Search3Args ab = a;
-      ab.qlist = a.bail_list;
-      ab.count_slot = a.bail_slot;
-      ab.list_lo = 0;
-      ab.list_hi = INT64_MAX;
-      ab.setmask = nullptr;
-      ab.bail_ticks = 0u;
-      k_reset_pools<<<1, 64, 0, st>>>(a.counters); // (the walk has drawn from them)
-      launch_ev(c, false, k_fallback<L>, pgrid, 256, st, ab, *wide);
-    }
     else
       launch_ev(c, false, k_search3w<L, true>, wgrid, 64, st, hi);
+    if ((a.bail_ticks || a.step_budget) && wide)
+      given_up(a);
   }
-  else if (wide && pgrid && mode == 1)
+  else if (wide && pgrid && mode == 1 && a.qlist)
+  {
     launch_ev(c, false, k_fallback<L>, pgrid, 256, st, a, *wide);
+    if (a.step_budget)
+      given_up(a);
+  }
   else if (mode == 3)
   {
     const bool bail = a.bail_ticks && wide;
@@ -2049,21 +2074,14 @@ static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, uns
     else
       launch_ev(c, false, k_search3w<L, false>, wgrid, 64, st, a);
     if (bail)
-    {
-      // the queries of the batches the walk gave up on, one wavefront each (or the pooled
-      // lanes, should they be many)
-      Search3Args ab = a;
-      ab.qlist = a.bail_list;
-      ab.count_slot = a.bail_slot;
-      ab.use_hint = 1;
-      ab.setmask = nullptr;
-      ab.bail_ticks = 0u;
-      k_reset_pools<<<1, 64, 0, st>>>(a.counters); // (the walk has drawn from them)
-      launch_ev(c, false, k_fallback<L>, pgrid, 256, st, ab, *wide);
-    }
+      given_up(a);
   }
   else
+  {
     launch_ev(c, false, k_search3p<L>, pgrid, 256, st, a);
+    if (a.step_budget && wide)
+      given_up(a);
+  }
   unsigned rgrid = grid / 8 + 1; // (a block of four wavefronts weighs the sets of 2048 queries)
   // (at most twice the wavefronts the chip holds: beyond four million queries a wavefront
   // takes several chunks of 512 and weighs their marked queries 64 at a time, whichever chunk
@@ -2410,6 +2428,7 @@ static int run_search3(icpx_ctx* c)
   a.count_slot = 3;
   a.bail_slot = 2;
   a.small_limit = FALLBACK_SMALL;
+  a.step_budget = 0u;
   a.list_lo = 0;
   a.list_hi = INT64_MAX;
   a.cap2 = c->cap2;
@@ -2569,7 +2588,14 @@ static int run_search3(icpx_ctx* c)
     a.bail_ticks = (uint32_t)(us * 2400u / 64u); // (the shader clock at its 2.4 GHz: a lower clock makes the budget longer)
     c->bail_passes++;
   }
-  if (((use_local && mode == 1) || a.bail_ticks) && c->heaps[4].built)
+  // the pooled lanes give up on a query whose walk goes on and on (Search3Args::step_budget),
+  // given the tree that the kernel behind them serves such queries over
+  if (mode == 1 && c->step_budget > 0 && ensure_heap(c, 64) == ICPX_OK)
+  {
+    a.step_budget = (uint32_t)c->step_budget;
+    a.bail_list = c->d_bail;
+  }
+  if ((mode == 1 || a.bail_ticks) && c->heaps[4].built)
   {
     const Heap& h = c->heaps[4];
     wide.qpos = c->d_qpos;

@@ -345,6 +345,12 @@ struct Search3Args
   // for it, 5 ms for a list of 0.1 M where the wavefronts take 2; 0.3 M such queries cost the
   // wavefronts 25 ms and the pooled lanes, which hold that many at once, the same 5)
   uint32_t small_limit;
+  // The pooled lanes give up on a query after this many steps of its walk (0: never) and put
+  // it on bail_list as the wavefront walk does with a batch: a lane walks alone, a step of its
+  // wavefront's loop per box, and a query far off the surface (a stray point in the hole of a
+  // torus: tens of thousands of boxes within its bound) keeps its wavefront, and the pass,
+  // for 10 ms, which one wavefront per query over the 64-ary tree serves in 0.5.
+  uint32_t step_budget;
 };
 
 // the margin a query's search is widened by (see Search3Args::widen_max)
@@ -693,6 +699,9 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
   int32_t sec_id = -1;
   float widen = 0.f;                        // margin by which the walk looks farther (widen_of)
   bool have = false, fin = false, need_bt = false, atleaf = false;
+  bool gave = false;  // the query's walk was given up on (step_budget): it goes on bail_list
+  uint32_t steps = 0; // boxes and leaves this query's walk has met
+  const uint32_t budget = a.bail_list ? a.step_budget : 0u;
   bool dry = false; // the pools have run out (same for every lane of the wavefront)
   uint32_t tried = 0; // runs this wavefront has found used up
   const int64_t total = a.qlist ? (int64_t)a.counters[a.count_slot] : a.nq;
@@ -724,11 +733,28 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
     if (__popcll(mi) >= a.refill || __ballot(have && !fin) == 0ull)
     {
       // results of the finished queries
-      const bool f = have && fin;
+      const bool given = have && fin && gave;
+      const bool f = have && fin && !gave;
       const bool tie = f && cnt >= 2 && cnt <= RING3;
       const bool ovf = f && cnt > RING3;
       if (f && !tie && !ovf)
         a.hint[q] = (cnt == 1) ? ring[0][tid] : -1;
+      const unsigned long long mg = budget ? __ballot(given) : 0ull;
+      if (mg)
+      {
+        // (what is queued is left unscreened: the query starts again, one wavefront to itself,
+        // from the best found so far)
+        const int leader = __ffsll((long long)mg) - 1;
+        uint32_t base = 0;
+        if (lane == leader)
+          base = atomicAdd(&a.counters[a.bail_slot], (uint32_t)__popcll(mg));
+        base = __shfl(base, leader, 64);
+        if (given)
+        {
+          a.hint[q] = cnt >= 1 ? ring[0][tid] : -1;
+          a.bail_list[base + __popcll(mg & lt)] = (uint32_t)q;
+        }
+      }
       if (f && a.cert)
       {
         // (a certificate that the next few moves of this size would use up is not worth
@@ -803,6 +829,8 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
           have = true;
           need_bt = false;
           atleaf = false;
+          gave = false;
+          steps = 0;
           n = 1;
           trail = 0;
           cnt = 0;
@@ -894,6 +922,11 @@ __device__ __forceinline__ void search3p_body(const Search3Args& a, const Xf& T)
               atleaf = true;
           }
         }
+      }
+      if (budget && ++steps > budget && !fin)
+      {
+        fin = true;
+        gave = true;
       }
       if (!fin && !need_bt && !atleaf)
       {

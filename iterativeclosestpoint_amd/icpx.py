@@ -35,7 +35,7 @@ DEV_SYMBOLS = (
     "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local", "icpx_set_refill",
     "icpx_set_finalize", "icpx_set_lean", "icpx_set_anchor", "icpx_set_shard_order",
     "icpx_set_certify_min", "icpx_set_wave_blocks", "icpx_set_query_curve", "icpx_set_noisy_policy", "icpx_set_seed",
-    "icpx_set_weigh", "icpx_set_bail",
+    "icpx_set_weigh", "icpx_set_bail", "icpx_set_step_budget",
 )
 
 
@@ -112,6 +112,7 @@ def load():
     lib.icpx_set_persistent.argtypes = [vp, ci]
     lib.icpx_set_refill.argtypes = [vp, ci]
     lib.icpx_set_bail.argtypes = [vp, ci]
+    lib.icpx_set_step_budget.argtypes = [vp, ci]
     lib.icpx_set_finalize.argtypes = [vp, ci]
     lib.icpx_set_lean.argtypes = [vp, ci]
     lib.icpx_set_anchor.argtypes = [vp, ci]
@@ -255,6 +256,10 @@ class Context:
         """Microseconds after which a whole pass of the wavefront walk gives up on a batch:
         1 by the cloud's size (default), 0 never, else that many."""
         _chk(load().icpx_set_bail(self._h, int(microseconds)))
+
+    def set_step_budget(self, steps):
+        """Steps after which the pooled lanes give up on a query (0: never; default 512)."""
+        _chk(load().icpx_set_step_budget(self._h, int(steps)))
 
     def set_finalize(self, build):
         """0: by size; 1: sums in registers; 2: sums on the matrix core."""

@@ -1219,6 +1219,57 @@ def test_inputs_that_are_not_numbers(icpx, synth, small):
     ctx.close()
 
 
+@pytest.mark.gpu
+def test_strays_and_queries_the_pooled_lanes_give_up_on(icpx, synth, oracle):
+    """Points anywhere in the target's box among a cloud on its surface, no threshold: a lane
+    of the pooled kernel that walks alone takes a trip to memory per box, thousands for a
+    stray in the hole of the torus, so it gives the query up after a budget of steps and the
+    kernel behind serves it one wavefront to itself.  Rows with a budget of 32 steps (most
+    queries given up on), the default and none are the same, cold, hinted and with
+    certificates, and the oracle's on a sample that holds every stray."""
+    xyz, tri = synth.bumpy_torus(200, 100)
+    pts, f, fn = synth.sample_surface(xyz, tri, 150_000, seed=71)
+    lo, hi = xyz.min(0).astype(np.float64), xyz.max(0).astype(np.float64)
+    n = 600
+    stray = np.stack([synth.u01(73, k, n) for k in range(3)], -1) * (hi - lo) + lo
+    src = synth.apply(synth.rigid(ry=1.5, t=(0.01, 0.0, -0.01)), pts)
+    where = np.arange(n) * (len(src) // n)
+    src[where] = stray.astype(np.float32)
+    mesh = oracle.Mesh(xyz, tri)
+    pick = np.union1d(where, np.arange(0, len(src), 37))
+    rows = {}
+    for budget, knobs in ((32, dict(local=0, persistent=1)), (32, {}), (512, {}), (0, dict(local=0, persistent=1))):
+        ctx = icpx.Context(0)
+        ctx.set_step_budget(budget)
+        for k, v in knobs.items():
+            getattr(ctx, "set_" + k)(v)
+        ctx.set_target(xyz, tri)
+        ctx.set_source(src)
+        T = np.eye(4)
+        out = []
+        for i, m in enumerate((0, 0, 1e-5, 2e-3, 1e-5, 1e-6)):
+            T = synth.rigid(t=(m, -m, 0.5 * m)) @ T
+            got = ctx.correspond(T, step=1, max_dist=1e9)
+            out.append({k: got[k].copy() for k in ("cell", "dist", "closest")})
+            if budget == 32 and knobs and i == 0:
+                gave = ctx.debug_counters()["pool"]   # (the pass's third counter: queries given up on)
+                assert gave > len(src) // 4, gave
+        rows[(budget, bool(knobs))] = out
+        ctx.close()
+    base = rows[(0, True)]
+    for key, out in rows.items():
+        for i, (a, b) in enumerate(zip(base, out)):
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (key, i, k)
+    T = np.eye(4)
+    for i, m in enumerate((0, 0, 1e-5)):
+        T = synth.rigid(t=(m, -m, 0.5 * m)) @ T
+        if i != 1:
+            ref = mesh.correspond(src[pick], T=T, step=1, max_dist=1e9, grid=True)
+            for k in ("cell", "dist", "closest"):
+                assert np.array_equal(base[i][k][pick], ref[k]), (i, k)
+
+
 def _point_triangle_dist(q, P):
     """Distances from points q (n,3) to triangles P (m,3,3), all pairs, float64 (Ericson)."""
     a, b, c = P[None, :, 0], P[None, :, 1], P[None, :, 2]

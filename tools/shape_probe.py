@@ -128,6 +128,14 @@ def case(name):
         M = S.rigid(ry=5.0, t=(0.8 * d, -0.5 * d, 0.33 * d))
         pts = S.apply(np.linalg.inv(c["truth"]), c["source_xyz"])
         c.update(source_xyz=S.apply(M, pts), source_normals=None, metric=1, max_dist=1e9, truth=M)
+    elif name.startswith("strays"):  # C3's cloud with strays<n> of its points anywhere in the target's box, no threshold
+        n = int(name[6:])
+        c = S.config_c3()
+        lo, hi = c["target_xyz"].min(0).astype(np.float64), c["target_xyz"].max(0).astype(np.float64)
+        out = np.stack([S.u01(61, k, n) for k in range(3)], -1) * (hi - lo) + lo
+        src = c["source_xyz"].copy()
+        src[:: len(src) // n][:n] = S.apply(c["truth"], out)
+        c.update(source_xyz=src, source_normals=None, metric=1, max_dist=1e9)
     elif name == "cube":    # a million points on the twelve triangles of a cube
         v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float32)
         t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5],
