@@ -72,6 +72,12 @@ extern "C"
    * to the kernel behind them, one wavefront per query; 0: never.  Default 512. */
   int icpx_set_step_budget(icpx_ctx* ctx, int steps);
 
+  /* The wavefront walk sets a query aside, for the kernel behind it (one wavefront per query),
+   * whose first bound is more than `edges` of the mesh's edge lengths and eight times the
+   * geometric mean of its batch's; 0: never (the default).  For clouds with stray points
+   * and no distance threshold. */
+  int icpx_set_defer(icpx_ctx* ctx, int edges);
+
   /* The fused finalize: 0 (default) = by the size of the cloud; 1 = the build that keeps the
    * metric's sums in registers; 2 = the build that accumulates them on the matrix core
    * (v_mfma_f64_16x16x4_f64 over a 16-vector per row).  The two add the rows up in different

@@ -365,6 +365,10 @@ struct icpx_ctx
   // of the previous pass that choose the radius
   int use_local = 1;
   int refill_override = 0; // pooled kernels' refill threshold (0 = by regime)
+  int defer_edges = 0;     // the wavefront walk sets a query aside that is this many edge lengths out and
+                           // 64 times (squared) beyond its batch's geometric mean (0: never, the default:
+                           // the test and the launch behind cost a clean million-point cloud's cold
+                           // pass 0.07 ms of 0.92)
   int step_budget = 512;   // steps after which the pooled lanes give up on a query (0: never)
   int bail_mode = 1;       // whole passes of the wavefront walk give up on long batches: 0 never,
                            // 1 on a target whose triangles' sizes range widely, after a time that goes by
@@ -1098,6 +1102,16 @@ extern "C" int icpx_set_refill(icpx_ctx* c, int lanes)
   if (lanes < 0 || lanes > 64)
     return fail(ICPX_E_INVALID, "refill threshold must be 0 (by regime) or 1..64 lanes (got %d)", lanes);
   c->refill_override = lanes;
+  return ICPX_OK;
+}
+
+extern "C" int icpx_set_defer(icpx_ctx* c, int edges)
+{
+  if (!c)
+    return fail(ICPX_E_INVALID, "null context");
+  if (edges < 0)
+    return fail(ICPX_E_INVALID, "edge lengths must be 0 (never) or positive, got %d", edges);
+  c->defer_edges = edges;
   return ICPX_OK;
 }
 
@@ -2053,7 +2067,7 @@ static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, uns
       launch_ev(c, false, k_search3w<L, true, true>, wgrid, 64, st, hi);
     else
       launch_ev(c, false, k_search3w<L, true>, wgrid, 64, st, hi);
-    if ((a.bail_ticks || a.step_budget) && wide)
+    if ((a.bail_ticks || a.step_budget || a.defer_far > 0.f) && wide)
       given_up(a);
   }
   else if (wide && pgrid && mode == 1 && a.qlist)
@@ -2073,7 +2087,7 @@ static void launch_search3(icpx_ctx* c, const Search3Args& a, unsigned grid, uns
       launch_ev(c, false, k_search3w<L, false, true>, wgrid, 64, st, a);
     else
       launch_ev(c, false, k_search3w<L, false>, wgrid, 64, st, a);
-    if (bail)
+    if (bail || (a.defer_far > 0.f && wide))
       given_up(a);
   }
   else
@@ -2429,6 +2443,7 @@ static int run_search3(icpx_ctx* c)
   a.bail_slot = 2;
   a.small_limit = FALLBACK_SMALL;
   a.step_budget = 0u;
+  a.defer_far = 0.f;
   a.list_lo = 0;
   a.list_hi = INT64_MAX;
   a.cap2 = c->cap2;
@@ -2595,7 +2610,15 @@ static int run_search3(icpx_ctx* c)
     a.step_budget = (uint32_t)c->step_budget;
     a.bail_list = c->d_bail;
   }
-  if ((mode == 1 || a.bail_ticks) && c->heaps[4].built)
+  // ... and the wavefront walk sets aside the queries that are far out where their batch is
+  // not (Search3Args::defer_far: beyond that many of the mesh's edge lengths)
+  if (c->defer_edges > 0 && ensure_heap(c, 64) == ICPX_OK)
+  {
+    const float reach = (float)c->defer_edges * c->mesh_edge;
+    a.defer_far = reach * reach;
+    a.bail_list = c->d_bail;
+  }
+  if ((mode == 1 || a.bail_ticks || a.defer_far > 0.f) && c->heaps[4].built)
   {
     const Heap& h = c->heaps[4];
     wide.qpos = c->d_qpos;

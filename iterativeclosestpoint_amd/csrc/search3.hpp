@@ -351,6 +351,11 @@ struct Search3Args
   // torus: tens of thousands of boxes within its bound) keeps its wavefront, and the pass,
   // for 10 ms, which one wavefront per query over the 64-ary tree serves in 0.5.
   uint32_t step_budget;
+  // The wavefront walk sets a query aside before its batch's walk (onto bail_list, for the
+  // kernel behind) when its first bound, the squared distance of its seed or hinted triangle,
+  // is above this (0: never) and 64 times the geometric mean of its batch's: a stray point
+  // among points on the surface, whose thousands of boxes the 63 others would sit through.
+  float defer_far;
 };
 
 // the margin a query's search is widened by (see Search3Args::widen_max)
@@ -1553,6 +1558,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
           ring[0][lane] = hs;
           cnt = 1;
           hs_used = hs;
+        }
+      }
+    }
+
+    if (a.defer_far > 0.f && a.bail_list)
+    {
+      const bool seeded = active && cnt == 1;
+      const float sd = seeded ? fmaxf((float)best, 1e-37f) : 1.f;
+      const float lg = seeded ? __log2f(sd) : 0.f;
+      float sum = lg;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1)
+        sum += __shfl_xor(sum, m, 64);
+      const int ns = __popcll(__ballot(seeded));
+      const bool far = seeded && ns >= 16 && sd > a.defer_far && lg > sum / (float)ns + 6.f;
+      const unsigned long long mf = __ballot(far);
+      if (mf) [[unlikely]]
+      {
+        uint32_t tb = 0u;
+        if (lane == 0)
+          tb = atomicAdd(&a.counters[a.bail_slot], (uint32_t)__popcll(mf));
+        tb = uni32(tb);
+        if (far)
+        {
+          a.hint[q] = ring[0][lane];
+          a.bail_list[tb + (uint32_t)__popcll(mf & lt)] = (uint32_t)q;
+          // (an idle lane from here on: its bound is below every distance)
+          active = false;
+          bboxf = -1.f;
+          cnt = 0;
         }
       }
     }

@@ -35,7 +35,7 @@ DEV_SYMBOLS = (
     "icpx_set_persistent", "icpx_debug_dump", "icpx_set_local", "icpx_set_refill",
     "icpx_set_finalize", "icpx_set_lean", "icpx_set_anchor", "icpx_set_shard_order",
     "icpx_set_certify_min", "icpx_set_wave_blocks", "icpx_set_query_curve", "icpx_set_noisy_policy", "icpx_set_seed",
-    "icpx_set_weigh", "icpx_set_bail", "icpx_set_step_budget",
+    "icpx_set_weigh", "icpx_set_bail", "icpx_set_step_budget", "icpx_set_defer",
 )
 
 
@@ -113,6 +113,7 @@ def load():
     lib.icpx_set_refill.argtypes = [vp, ci]
     lib.icpx_set_bail.argtypes = [vp, ci]
     lib.icpx_set_step_budget.argtypes = [vp, ci]
+    lib.icpx_set_defer.argtypes = [vp, ci]
     lib.icpx_set_finalize.argtypes = [vp, ci]
     lib.icpx_set_lean.argtypes = [vp, ci]
     lib.icpx_set_anchor.argtypes = [vp, ci]
@@ -260,6 +261,11 @@ class Context:
     def set_step_budget(self, steps):
         """Steps after which the pooled lanes give up on a query (0: never; default 512)."""
         _chk(load().icpx_set_step_budget(self._h, int(steps)))
+
+    def set_defer(self, edges):
+        """Edge lengths beyond which the wavefront walk sets a query aside that is far out
+        where its batch is not (0: never, the default)."""
+        _chk(load().icpx_set_defer(self._h, int(edges)))
 
     def set_finalize(self, build):
         """0: by size; 1: sums in registers; 2: sums on the matrix core."""

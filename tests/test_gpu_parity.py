@@ -1238,7 +1238,9 @@ def test_strays_and_queries_the_pooled_lanes_give_up_on(icpx, synth, oracle):
     mesh = oracle.Mesh(xyz, tri)
     pick = np.union1d(where, np.arange(0, len(src), 37))
     rows = {}
-    for budget, knobs in ((32, dict(local=0, persistent=1)), (32, {}), (512, {}), (0, dict(local=0, persistent=1))):
+    # (... and the wavefront walk with the strays set aside before their batches' walks)
+    for budget, knobs in ((32, dict(local=0, persistent=1)), (32, {}), (512, {}), (512, dict(defer=1, persistent=3)),
+                          (0, dict(local=0, persistent=1))):
         ctx = icpx.Context(0)
         ctx.set_step_budget(budget)
         for k, v in knobs.items():
@@ -1254,9 +1256,12 @@ def test_strays_and_queries_the_pooled_lanes_give_up_on(icpx, synth, oracle):
             if budget == 32 and knobs and i == 0:
                 gave = ctx.debug_counters()["pool"]   # (the pass's third counter: queries given up on)
                 assert gave > len(src) // 4, gave
-        rows[(budget, bool(knobs))] = out
+            if "defer" in knobs and i == 1:
+                aside = ctx.debug_counters()["pool"]
+                assert n // 2 < aside <= n, aside   # (the strays, and nobody else)
+        rows[(budget, tuple(sorted(knobs)))] = out
         ctx.close()
-    base = rows[(0, True)]
+    base = rows[(0, ("local", "persistent"))]
     for key, out in rows.items():
         for i, (a, b) in enumerate(zip(base, out)):
             for k in a:

@@ -22,8 +22,8 @@ from iterativeclosestpoint_amd import icpx, synth as S  # noqa: E402
 KNOBS = dict(
     local=[0, 1, 2, 3], persistent=[1, 3, 4], bail=[0, 1, 2, 20, 200], certify_min=[1000, 100_000, 4_000_000],
     noisy_policy=[0, 1], weigh=[0, 1, 2, 3], seed=[0, 1, 2], query_curve=[0, 1], finalize=[0, 1, 2],
-    lean=[0, 1, 2, 3], anchor=[0, 1], wave_blocks=[1, 2, 8], step_budget=[0, 48, 4096])
-PLAIN = dict(local=0, persistent=1, bail=0, lean=0, anchor=0, step_budget=0)
+    lean=[0, 1, 2, 3], anchor=[0, 1], wave_blocks=[1, 2, 8], step_budget=[0, 48, 4096], defer=[0, 1, 8])
+PLAIN = dict(local=0, persistent=1, bail=0, lean=0, anchor=0, step_budget=0, defer=0)
 
 
 def odd_scenes():
