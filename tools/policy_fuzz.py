@@ -59,6 +59,15 @@ def scenes(big, only=None):
             cloud = cloud + np.stack([S.gaussian(43, 2 * k, npts * mul) for k in range(3)], -1) * noise
         M = S.rigid(ry=3.0, t=(0.01, 0.01, -0.01))
         yield name, xyz, tri, S.apply(M, cloud), 10.0
+    if not only or "strays" in only:
+        # one point in fifty anywhere in the target's box, no threshold
+        xyz, tri = S.bumpy_torus(nu, nv)
+        n = 300_000 * mul
+        pts, f, fn = S.sample_surface(xyz, tri, n, seed=45)
+        lo, hi = xyz.min(0).astype(np.float64), xyz.max(0).astype(np.float64)
+        cloud = pts.astype(np.float64)
+        cloud[::50] = np.stack([S.u01(47, k, len(cloud[::50])) for k in range(3)], -1) * (hi - lo) + lo
+        yield "strays", xyz, tri, S.apply(S.rigid(ry=3.0, t=(0.01, 0.01, -0.01)), cloud), 1e9
     if only and "partial" not in only:
         return
     # partial overlap, a fifth of the cloud outliers, a threshold of 2 % of the diagonal
