@@ -79,6 +79,29 @@ def test_solve_rank_deficient_and_few():
     assert np.allclose(M, [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, -0.25], [0, 0, 0, 1]], atol=1e-12)
 
 
+@pytest.mark.parametrize("metric", (0, 1, 2))
+def test_loop_ends_on_a_transform_that_is_not_usable(metric):
+    """Sums that carry a NaN (from normals that are not numbers) make a solve whose transform
+    no search could take: the loop ends with RUN_DIVERGED and the last good transform (the
+    device's loop does the same in state.hpp; the reference goes on with the NaN)."""
+    g = np.stack(np.meshgrid(np.linspace(-1, 1, 9), np.linspace(-1, 1, 9)), -1).reshape(-1, 2)
+    t = np.concatenate([g, 0.1 * np.sin(3 * g[:, :1]) * np.cos(2 * g[:, 1:])], 1).astype(np.float32)
+    nrm = np.tile(np.float32([0, 0, 1]), (len(g), 1))
+    s = (t + np.float32([0.01, -0.02, 0.05])).astype(np.float32)
+    good = sums_from_rows(metric, s, t, nrm, nrm, np.zeros(3))
+    bad = good.copy()
+    bad[8 if metric == 0 else 12] = np.nan
+    calls = []
+
+    def accumulate(T):
+        calls.append(T.copy())
+        return good if len(calls) <= 2 else bad
+
+    T, it, md, st = icp_loop(accumulate, None, np.zeros(3), metric, 10, False, 0.0)
+    assert st == icpx.RUN_DIVERGED and it == 2 and len(calls) == 3
+    assert np.isfinite(T).all() and np.array_equal(T, calls[2])   # (the last transform searched with)
+
+
 def oracle_accumulate(mesh, src, sn, metric, step, max_dist, origin, k0=0, k1=None):
     """Per-shard sums as the GPU would produce them, from oracle rows."""
     def acc(T):
